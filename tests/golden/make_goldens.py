@@ -1,0 +1,388 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference (grunwaldlab/krisp) in the
+build container.  This script is the only place that imports /root/reference;
+it is never executed on the GPU box (the reference tree does not travel) and
+nothing else in the repo imports it.  Its outputs -- the *.json / *.gz data
+files next to it -- are plain input/expected-output vectors.
+
+How the reference is imported:
+  * krisp.kstream imports as-is (stdlib only).
+  * krisp.krisp_fasta.* import colorama, primer3, prettytable and
+    Bio.Data.IUPACData at module top; none is installed (no network).  They are
+    registered as in-memory placeholder modules: colours -> '', primer3 /
+    PrettyTable -> never called (no --primer3 case is generated), and
+    IUPACData.ambiguous_dna_values -> the standard IUPAC DNA table.  Only that
+    table influences output (the CSV consensus letter, Amplicon.py:10-12,65);
+    README.md:121-123 pins AC->M and GT->K of it.
+
+Usage:  python3 tests/golden/make_goldens.py        (from the repo root)
+"""
+import gzip
+import hashlib
+import io
+import json
+import os
+import random
+import shutil
+import sys
+import tempfile
+import types
+from contextlib import redirect_stdout
+from pathlib import Path
+
+REF = "/root/reference"
+HERE = Path(__file__).resolve().parent
+sys.dont_write_bytecode = True
+sys.path.insert(0, f"{REF}/src")
+
+
+def _install_placeholders():
+    col = types.ModuleType("colorama")
+
+    class _Blank:
+        def __getattr__(self, name):
+            return ""
+    col.Fore = col.Back = col.Style = _Blank()
+    sys.modules["colorama"] = col
+    p3 = types.ModuleType("primer3")
+    sys.modules["primer3"] = p3
+    pt = types.ModuleType("prettytable")
+    pt.PrettyTable = object
+    sys.modules["prettytable"] = pt
+    bio = types.ModuleType("Bio")
+    data = types.ModuleType("Bio.Data")
+    iu = types.ModuleType("Bio.Data.IUPACData")
+    iu.ambiguous_dna_values = {
+        "A": "A", "C": "C", "G": "G", "T": "T", "M": "AC", "R": "AG",
+        "W": "AT", "S": "CG", "Y": "CT", "K": "GT", "V": "ACG", "H": "ACT",
+        "D": "AGT", "B": "CGT", "X": "GATC", "N": "GATC"}
+    bio.Data = data
+    data.IUPACData = iu
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.Data"] = data
+    sys.modules["Bio.Data.IUPACData"] = iu
+
+
+_install_placeholders()
+from krisp.kstream import kstream  # noqa: E402
+from krisp.krisp_fasta import krisp_fasta as KF  # noqa: E402
+from krisp.krisp_fasta.intersectAmplicons import mergeFiles  # noqa: E402
+from krisp.krisp_fasta.filterAlignments import filterAlignments  # noqa: E402
+from krisp.krisp_fasta.shared import simplename  # noqa: E402
+from krisp.krisp_fasta.Amplicon import ConservedEndAmplicons  # noqa: E402
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+# --------------------------------------------------------------------------
+# 1. kstream-level cases
+# --------------------------------------------------------------------------
+def run_kstream(kwargs, seqs=None, file_text=None, fname="in.fa", use_write=False):
+    """Returns {'out': [...]} or {'raises': 'KeyError'}"""
+    with tempfile.TemporaryDirectory() as td:
+        src = seqs
+        if file_text is not None:
+            src = os.path.join(td, fname)
+            if fname.endswith(".gz"):
+                with gzip.open(src, "wt") as f:
+                    f.write(file_text)
+            else:
+                with open(src, "w") as f:
+                    f.write(file_text)
+        try:
+            ks = kstream(**kwargs)
+            if use_write:
+                outp = os.path.join(td, "out.txt")
+                n = ks.write(outp, src)
+                with open(outp) as f:
+                    lines = f.read().split("\n")
+                assert lines[-1] == ""
+                return {"out": lines[:-1], "count": n}
+            return {"out": list(ks(src))}
+        except Exception as e:  # noqa: BLE001
+            return {"raises": type(e).__name__, "msg": str(e)}
+
+
+def kstream_cases():
+    cases = []
+
+    def add(name, kwargs, seqs=None, file_text=None, fname="in.fa", use_write=False):
+        res = run_kstream(kwargs, seqs, file_text, fname, use_write)
+        cases.append({"name": name, "kwargs": kwargs, "seqs": seqs,
+                      "file_text": file_text, "fname": fname,
+                      "use_write": use_write, **res})
+
+    kf = dict(kmers=6, complements=True, disallow="Nn", split=[3, -1],
+              sort=True, sortcols=[0, 2])
+    adv = "ACGTacgtNACGTTRACGTA"
+    add("adv_mapsoft", dict(kf, mapsoft=True), [adv])
+    add("adv_omitsoft", dict(kf, omitsoft=True), [adv])
+    add("adv_mapsoft_write", dict(kf, mapsoft=True), [adv], use_write=True)
+    add("palindrome", dict(kmers=4, complements=True), ["ACGT"])
+    add("split_R0", dict(kmers=6, split=[3, 0]), ["ACGTAC"])
+    add("split_L0", dict(kmers=6, split=[0, -2]), ["ACGTAC"])
+    add("split_int", dict(kmers=6, split=2), ["ACGTAC"])
+    add("rna", dict(kmers=4, complements=True), ["ACGUAC"])
+    add("rna_sorted_write", dict(kmers=4, complements=True, sort=True), ["ACGUAC", "UUGCA"], use_write=True)
+    add("illegal_X", dict(kmers=4, complements=True), ["ACGXAC"])
+    add("illegal_X_omit_lower", dict(kmers=4, complements=True, omitsoft=True), ["ACGxAC"])
+    add("illegal_dash_omit", dict(kmers=4, complements=True, omitsoft=True), ["ACG-AC"])
+    add("nonletter_only_omit", dict(kmers=3, complements=True, omitsoft=True), ["ACG123TT"])
+    add("omit_and_map", dict(kmers=4, omitsoft=True, mapsoft=True), ["ACGT"])
+    add("canon_and_comp", dict(kmers=4, canonicals=True, complements=True), ["ACGT"])
+    add("canonicals", dict(kmers=5, canonicals=True), ["ACGTTGCAAT", "TTTTTAAAAA"])
+    add("allow", dict(kmers=3, allow="ACGT"), ["ACGTNACGRT"])
+    add("disallow", dict(kmers=3, disallow="Nn"), ["ACGTNACnGT"])
+    add("expandiupac", dict(kmers=3, expandiupac=True), ["ARGNT"])
+    add("multi_k", dict(kmers=[3, 5]), ["ACGTAC", "GG", "TTTTT"])
+    add("no_k_passthrough", dict(complements=True), ["ACG", "TTA"])
+    add("sorted_plain", dict(kmers=3, sort=True), ["GATTACA"])
+    add("too_short", dict(kmers=8, complements=True), ["ACGT", "ACGTACGTA"])
+    fasta = ">r1 desc\nACGTAC\n  GTTA  \n\n>r2\n>r3\nAC\n>r4\nTTGACCA\nGG\n"
+    add("fasta_basic", dict(kmers=5, complements=True, disallow="Nn", mapsoft=True,
+                            split=[2, -2], sort=True, sortcols=[0, 2]),
+        file_text=fasta, fname="x.fasta")
+    add("fasta_gz_write", dict(kmers=5, complements=True, disallow="Nn", mapsoft=True,
+                               split=[2, -2], sort=True, sortcols=[0, 2]),
+        file_text=fasta, fname="x.fasta.gz", use_write=True)
+    nonfasta = "ACGTAC\n>notheader\nGGTTAA\n"
+    add("nonfasta_later_gt", dict(kmers=4), file_text=nonfasta, fname="x.txt")
+    add("fasta_header_midline", dict(kmers=4), file_text="AC>GT\nACGTA\n", fname="y.txt")
+    add("fasta_rna_file", dict(kmers=4, complements=True, sort=True),
+        file_text=">a\nACGUACGU\n>b\nGGUUAACC\n", fname="r.fa", use_write=True)
+    # random soft-masked / N / IUPAC genomes through the krisp_fasta combination
+    rng = random.Random(7)
+    for i, (L, D, R) in enumerate([(3, 1, 2), (4, 2, 3), (5, 0, 5), (2, 3, 0), (0, 2, 3), (7, 1, 2)]):
+        recs = []
+        for r in range(3):
+            n = rng.randint(5, 60)
+            s = "".join(rng.choice("ACGT" * 10 + "acgt" * 2 + "NnRYK") for _ in range(n))
+            recs.append(s)
+        text = "".join(f">rec{j}\n{s}\n" for j, s in enumerate(recs))
+        for mode in ("mapsoft", "omitsoft"):
+            kw = dict(kmers=L + D + R, complements=True, disallow="Nn",
+                      split=[L, -R], sort=True, sortcols=[0, 2])
+            kw[mode] = True
+            add(f"rand{i}_{mode}_{L}_{D}_{R}", kw, file_text=text, fname=f"g{i}.fa", use_write=True)
+    return cases
+
+
+# --------------------------------------------------------------------------
+# 2. krisp_fasta-level cases (stages + final text)
+# --------------------------------------------------------------------------
+def canon_lines(path):
+    with open(path) as f:
+        lines = [ln for ln in f.read().split("\n") if ln]
+    return sorted(lines)
+
+
+def run_fasta_case(name, files, ingroup, outgroup, L, D, R, omit=False, dot=False,
+                   keep_sorted=False, main_args=None, run_main=True):
+    """files: {filename: bytes}.  Runs stages (for intermediates) and main()
+    (for the final text), both with cores=1."""
+    k = L + D + R
+    out = {"name": name, "ingroup": ingroup, "outgroup": outgroup, "L": L, "D": D,
+           "R": R, "omit_soft": omit, "dot": dot}
+    with tempfile.TemporaryDirectory() as td:
+        paths = {}
+        for fn, content in files.items():
+            p = os.path.join(td, fn)
+            with open(p, "wb") as f:
+                f.write(content)
+            paths[fn] = p
+        work = os.path.join(td, "work")
+        os.mkdir(work)
+        # ---- stages
+        kfiles = []
+        sorted_info = {}
+        for fn in ingroup + outgroup:
+            kf = f"{work}/{KF.basename(Path(fn).name)}.{k}mers"
+            KF.extractSortedKmers(paths[fn], L, R, k, kf, "80%", 1, False, omit)
+            data = open(kf, "rb").read()
+            sorted_info[fn] = {"sha256": sha(data), "lines": data.count(b"\n"),
+                               "bytes": len(data)}
+            if keep_sorted and fn == ingroup[0]:
+                with gzip.GzipFile(HERE / f"{name}.{fn}.{k}mers.gz", "wb", mtime=0) as g:
+                    g.write(data)
+            kfiles.append(kf)
+        out["sorted"] = sorted_info
+        merged = f"{work}/merged_file.txt"
+        mergeFiles(list(kfiles), merged, 1, work, False)
+        out["merged_canon"] = canon_lines(merged)
+        if k > L + R:
+            filt = f"{work}/filtered.txt"
+            filterAlignments(merged, filt, frozenset(simplename(f) for f in ingroup))
+            out["filtered_canon"] = canon_lines(filt)
+        if not run_main:
+            # the reference's renderer dies with KeyError when a column holds a
+            # lone IUPAC letter (Amplicon.py:65); only the stages are pinned
+            return out
+        # ---- main()
+        csvp = os.path.join(td, "out.csv")
+        alnp = os.path.join(td, "out.txt")
+        argv = ["krisp_fasta"] + [paths[f] for f in ingroup]
+        if outgroup:
+            argv += ["--outgroup"] + [paths[f] for f in outgroup]
+        if main_args is None:
+            main_args = ["--conserved-left", str(L), "--conserved-right", str(R),
+                         "--diagnostic", str(D)]
+        argv += main_args
+        if omit:
+            argv += ["--omit-soft"]
+        if dot:
+            argv += ["--dot-alignment"]
+        argv += ["--cores", "1", "--workdir", work, "--out_csv", csvp, "--out_align", alnp]
+        out["main_args"] = main_args
+        old = sys.argv
+        ConservedEndAmplicons.ENABLE_DOT = False
+        try:
+            sys.argv = argv
+            KF.main()
+        finally:
+            sys.argv = old
+        out["csv"] = open(csvp).read()
+        out["align"] = open(alnp).read() if os.path.exists(alnp) else ""
+    return out
+
+
+def mutate(rng, s, rate):
+    o = []
+    for c in s:
+        if rng.random() < rate:
+            c = rng.choice([b for b in "ACGT" if b != c])
+        o.append(c)
+    return "".join(o)
+
+
+def fasta_text(records, width=60):
+    o = []
+    for i, s in enumerate(records):
+        o.append(f">rec{i}")
+        for j in range(0, len(s), width):
+            o.append(s[j:j + width])
+    return ("\n".join(o) + "\n").encode()
+
+
+def fasta_cases():
+    cases = []
+    # ---- C1: the reference's own test data
+    c1 = {}
+    names = ["ingroup0", "ingroup1", "outgroup0", "outgroup1", "outgroup2"]
+    os.makedirs(HERE / "c1", exist_ok=True)
+    for n in names:
+        fn = f"{n}.fasta.gz"
+        src = f"{REF}/test_data/krisp_fasta/{fn}"
+        shutil.copyfile(src, HERE / "c1" / fn)
+        os.chmod(HERE / "c1" / fn, 0o644)
+        c1[fn] = open(src, "rb").read()
+    ing = [f"{n}.fasta.gz" for n in names[:2]]
+    outg = [f"{n}.fasta.gz" for n in names[2:]]
+    cases.append(run_fasta_case("c1_25_1_2", c1, ing, outg, 25, 1, 2, keep_sorted=True))
+    cases.append(run_fasta_case("c1_25_1_2_dot", c1, ing, outg, 25, 1, 2, dot=True))
+    cases.append(run_fasta_case("c1_28_1_2", c1, ing, outg, 28, 1, 2))
+    cases.append(run_fasta_case("c1_30_40_30", c1, ing, outg, 30, 40, 30,
+                                main_args=["--conserved", "30", "--amplicon", "100"]))
+    cases.append(run_fasta_case("c1_30_40_30_dot", c1, ing, outg, 30, 40, 30, dot=True,
+                                main_args=["--conserved", "30", "--amplicon", "100"]))
+    cases.append(run_fasta_case("c1_30_0_30_all_ingroup", c1, ing + outg, [], 30, 0, 30,
+                                main_args=["--conserved", "30", "--diagnostic", "0"]))
+    cases.append(run_fasta_case("c1_32_60_32", c1, ing, outg, 32, 60, 32))
+    cases.append(run_fasta_case("c1_10_2_4_amplicon_diag", c1, ing, outg, 7, 2, 7,
+                                main_args=["--amplicon", "16", "--diagnostic", "2"]))
+    # ---- four-genome label case
+    Lq, Rq = "ACGTTGCA", "GGATC"
+    lab = {
+        "inA.fa": fasta_text([Lq + "T" + Rq, Lq + "T" + Rq, Lq + "G" + Rq]),
+        "inB.fasta": fasta_text([Lq + "T" + Rq]),
+        "outX.v1.fna": fasta_text([Lq + "C" + Rq]),
+        "outY.fa": fasta_text([Lq + "A" + Rq + "NN" + Lq + "C" + Rq]),
+    }
+    cases.append(run_fasta_case("labels_8_1_5", lab, ["inA.fa", "inB.fasta"],
+                                ["outX.v1.fna", "outY.fa"], 8, 1, 5))
+    cases.append(run_fasta_case("labels_8_1_5_noout", lab,
+                                ["inA.fa", "inB.fasta", "outX.v1.fna", "outY.fa"], [], 8, 1, 5))
+    cases.append(run_fasta_case("labels_8_1_5_dot", lab, ["inA.fa", "inB.fasta"],
+                                ["outX.v1.fna", "outY.fa"], 8, 1, 5, dot=True))
+    cases.append(run_fasta_case("labels_swapped_order", lab, ["inB.fasta", "inA.fa"],
+                                ["outY.fa", "outX.v1.fna"], 8, 1, 5))
+    # ---- related random genomes (seeded) -- many groups, repeats, soft mask, N
+    rng = random.Random(20241008)
+    for ci, (n_in, n_out, glen, L, D, R, omit, rate, iupac) in enumerate([
+            (2, 2, 600, 6, 1, 2, False, 0.02, False),
+            (2, 3, 900, 5, 2, 4, False, 0.03, False),
+            (3, 2, 700, 7, 1, 3, True, 0.02, False),
+            (1, 1, 500, 4, 3, 4, False, 0.05, False),
+            (2, 1, 800, 9, 0, 9, False, 0.01, False),
+            (3, 0, 500, 5, 1, 5, False, 0.04, False),
+            (2, 2, 1200, 12, 4, 12, False, 0.01, False),
+            (2, 2, 1500, 16, 1, 15, False, 0.005, False),
+            (2, 2, 600, 3, 1, 0, False, 0.02, False),      # R = 0 quirk
+            (2, 2, 2000, 20, 10, 20, False, 0.004, False),  # k = 50 > 32
+            (2, 2, 3000, 32, 6, 32, True, 0.003, False),   # k = 70 > 32, omit-soft
+            (2, 2, 600, 5, 1, 3, False, 0.02, True),        # IUPAC letters kept
+            (4, 5, 900, 8, 1, 4, False, 0.01, False),       # 9 genomes, odd tree
+            (2, 2, 1500, 14, 2, 14, False, 0.004, False),   # k = 30
+            (1, 2, 1200, 15, 2, 15, False, 0.004, False),   # k = 32
+    ]):
+        anc_recs = []
+        for r in range(3):
+            s = "".join(rng.choice("ACGT") for _ in range(glen // 3))
+            # plant a tandem repeat and a palindrome so duplicates / (2) labels occur
+            if r == 0:
+                unit = "".join(rng.choice("ACGT") for _ in range(L + D + R + 3))
+                s = s[:50] + unit * 3 + s[50:]
+            anc_recs.append(s)
+        files = {}
+        ing, outg = [], []
+        # planted ingroup-specific SNPs: (record, position, ingroup base, outgroup base)
+        plants = []
+        for r in range(3):
+            for _ in range(3):
+                pos = rng.randrange(L + D + R, len(anc_recs[r]) - (L + D + R))
+                b1, b2 = rng.sample("ACGT", 2)
+                plants.append((r, pos, b1, b2))
+        for gi in range(n_in + n_out):
+            recs = []
+            for r, s in enumerate(anc_recs):
+                m = mutate(rng, s, rate)
+                m = list(m)
+                for (pr, pos, b1, b2) in plants:
+                    if pr == r:
+                        m[pos] = b1 if gi < n_in else b2
+                # soft-mask a stretch and drop in a few N / IUPAC letters
+                a = rng.randrange(0, max(1, len(m) - 40))
+                for j in range(a, min(len(m), a + rng.randint(0, 30))):
+                    m[j] = m[j].lower()
+                for _ in range(rng.randint(0, 2)):
+                    m[rng.randrange(len(m))] = rng.choice("NnRYKM" if iupac else "Nn")
+                recs.append("".join(m))
+            fn = (f"in{gi}.fa" if gi < n_in else f"out{gi - n_in}.fasta")
+            files[fn] = fasta_text(recs)
+            (ing if gi < n_in else outg).append(fn)
+        cases.append(run_fasta_case(f"rand{ci}_{L}_{D}_{R}", files, ing, outg, L, D, R, omit=omit,
+                                    run_main=not iupac))
+        cases[-1]["files"] = {fn: c.decode() for fn, c in files.items()}
+    for c in cases:
+        if c["name"].startswith("labels"):
+            c["files"] = {fn: v.decode() for fn, v in lab.items()}
+    return cases
+
+
+def main():
+    ks = kstream_cases()
+    with open(HERE / "kstream_cases.json", "w") as f:
+        json.dump(ks, f, indent=1)
+    print(f"kstream cases: {len(ks)}")
+    fc = fasta_cases()
+    with open(HERE / "fasta_cases.json", "w") as f:
+        json.dump(fc, f, indent=1)
+    print(f"krisp_fasta cases: {len(fc)}")
+    for c in fc:
+        print(c["name"], "merged", len(c["merged_canon"]), "filtered",
+              len(c.get("filtered_canon", [])), "csv bytes", len(c.get("csv", "")))
+
+
+if __name__ == "__main__":
+    main()
