@@ -1,0 +1,136 @@
+/* krisp_hip.h -- C ABI of libkrisp_hip.so: the MI355X (gfx950) replacement for
+ * krisp_fasta's k-mer generation / sort / multi-genome intersection hot path.
+ *
+ * The reference (grunwaldlab/krisp @ 2024_10_08) is pure Python and has no FFI
+ * layer; the seams these entry points replace are (file:line into
+ * /root/reference/src/krisp):
+ *
+ *   kr_genome_upload + kr_genome_sort   krisp_fasta/krisp_fasta.py:16-66 extractSortedKmers
+ *        = kstream(...).write():        kstream/kstream.py:250-325 (generate: 617-677, 715-766,
+ *                                       805-832) + sortInPlace kstream/kstream.py:83-119 (GNU sort)
+ *   kr_genome_fetch_keys                the sorted "{left},{diag},{right}" k-mer file
+ *                                       (krisp_fasta.py:241-243), as packed integers
+ *   kr_intersect                        krisp_fasta/intersectAmplicons.py:232-310 mergeFiles
+ *                                       (pairwise tree of shared.py:321-347 intersectSortedStreams)
+ *                                       + filterAlignments.py:31-40 / Amplicon.py:495-521
+ *   kr_cands_merge                      the same intersect applied to candidate lists that were
+ *                                       produced on other GPUs (no reference counterpart: the
+ *                                       reference is single-host)
+ *   kr_collect + kr_fetch               the merged / filtered file: one (sequence, genome,
+ *                                       multiplicity) triple per label of each line
+ *                                       (Amplicon.py:170-187, 330-348)
+ *
+ * Conventions: plain C, no exceptions cross the boundary, every host buffer is
+ * caller-allocated and caller-owned, a negative return value is an error code
+ * (text via kr_last_error).  One context = one GPU = one HIP stream; a context
+ * is not thread-safe, distinct contexts may be driven from distinct threads.
+ * ctypes releases the GIL around each call.
+ *
+ * KEY FORMAT.  A window w of k = L+D+R bases (k <= 32) is split as
+ * left = w[0:L], diag = w[L:L+D], right = w[L+D:k] (kstream.py:805-832 with
+ * split=[L,-R]).  Its key is the string left|right|diag, 2 bits per base
+ * (A=0 C=1 G=2 T=3), base j in bits 63-2j..62-2j, low bits zero.  Unsigned
+ * integer order of keys == the reference's sort order (left, right, diag)
+ * (GNU sort -t, -k1,1 -k3,3 with its whole-line last-resort compare).
+ *
+ * INPUT FORMAT.  `bases` is the ASCII text of the FASTA records of one genome,
+ * records separated by ONE '\n' byte (no headers).  Windows never span a
+ * separator.  Upper/lower-case ACGT, N/n are handled on the device; IUPAC
+ * ambiguity letters and characters outside the reference's COMP_MAP
+ * (kstream.py:11-18) must be resolved by the host before upload (the Python
+ * host layer does so) -- on the device they simply invalidate their windows.
+ */
+#ifndef KRISP_HIP_H
+#define KRISP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kr_ctx kr_ctx;
+
+/* candidate window: (left,right) prefix present in every genome, plus, per
+ * diagnostic column c (c < D <= 16) the set of bases seen at that column in
+ * ingroup / outgroup genomes (bit 4c+b). */
+typedef struct { uint64_t prefix, in_mask, out_mask; } kr_cand;
+
+/* one distinct k-mer of one genome under a candidate prefix, with its multiplicity */
+typedef struct { uint64_t key; uint32_t genome; uint32_t count; } kr_record;
+
+enum {
+    KR_OK = 0,
+    KR_ERR_HIP = -1,       /* a HIP runtime call failed */
+    KR_ERR_PARAM = -2,     /* bad argument (k > 32, D > 16, unknown genome id ...) */
+    KR_ERR_CAPACITY = -3,  /* caller buffer too small / hbm budget exceeded */
+    KR_ERR_STATE = -4      /* call sequence error (e.g. intersect before sort) */
+};
+
+enum { KR_SOFT_MAP = 0,    /* lower case -> upper case (krisp_fasta default, krisp_fasta.py:33-43) */
+       KR_SOFT_OMIT = 1 }; /* drop windows holding lower case (--omit-soft, krisp_fasta.py:21-31) */
+
+/* stages with device timers (kr_stage_ms) */
+enum { KR_ST_PACK = 0, KR_ST_HIST, KR_ST_SCAN, KR_ST_SCATTER1, KR_ST_SCATTER2, KR_ST_LOCALSORT,
+       KR_ST_FALLBACK, KR_ST_INTERSECT, KR_ST_COMPACT, KR_ST_COLLECT, KR_ST_MERGE, KR_ST_COUNT };
+
+kr_ctx*     kr_create(int device, size_t hbm_budget_bytes);   /* budget 0 = no limit */
+void        kr_destroy(kr_ctx*);
+const char* kr_last_error(kr_ctx*);                            /* ctx may be NULL */
+
+/* Key geometry + soft-mask rule for every genome of this context.
+ * max_bases = length of the largest genome that will be uploaded (sizes the
+ * radix fan-out so that all genomes share one bucket grid). */
+int kr_set_params(kr_ctx*, int L, int D, int R, int softmask_mode, size_t max_bases);
+
+/* H2D copy of one genome's text + all device allocations it needs. */
+int kr_genome_upload(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
+/* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous. */
+int kr_genome_sort(kr_ctx*, int genome_id);
+/* upload + sort + sync; returns the number of k-mer records (>= 0). */
+int64_t kr_genome_add(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
+int64_t kr_genome_count(kr_ctx*, int genome_id);               /* syncs */
+int64_t kr_genome_fetch_keys(kr_ctx*, int genome_id, uint64_t* out, size_t cap);
+int     kr_genome_free(kr_ctx*, int genome_id);
+
+/* n-way intersection on the (left,right) prefix over sorted genomes.
+ * is_ingroup[i] != 0 marks genome_ids[i] as ingroup.  apply_filter != 0 keeps
+ * only candidates with a column whose ingroup and outgroup base sets are
+ * disjoint (skipped when D == 0, krisp_fasta.py:265).  Returns #candidates. */
+int64_t kr_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup,
+                     int apply_filter);
+int64_t kr_cands_count(kr_ctx*);
+int64_t kr_cands_fetch(kr_ctx*, kr_cand* out, size_t cap);
+/* Replace the candidate set (sorted by prefix, unique). */
+int64_t kr_cands_load(kr_ctx*, const kr_cand* cands, size_t n);
+/* candidates := candidates INTERSECT other (sorted, unique), masks OR-ed;
+ * other == NULL / n == 0 with apply_filter just filters.  Returns the new count. */
+int64_t kr_cands_merge(kr_ctx*, const kr_cand* other, size_t n, int have_other, int apply_filter);
+
+/* For every candidate and every listed genome: its distinct keys + multiplicities.
+ * Returns #records; fetch them (unordered) with kr_fetch. */
+int64_t kr_collect(kr_ctx*, const int* genome_ids, int n);
+int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
+
+int     kr_sync(kr_ctx*);
+/* HIP-event timers on the context's stream */
+int     kr_timer_begin(kr_ctx*);
+double  kr_timer_end_ms(kr_ctx*);                              /* syncs */
+/* accumulated device time of one stage since the last kr_stage_reset (syncs);
+ * only collected after kr_stage_enable(ctx, 1) (it serialises launches). */
+int     kr_stage_enable(kr_ctx*, int on);
+int     kr_stage_reset(kr_ctx*);
+double  kr_stage_ms(kr_ctx*, int stage);
+int64_t kr_stage_launches(kr_ctx*, int stage);
+
+/* introspection for stage-level parity tests: 0 codes(u64) 1 bad(u32) 2 hist(u32)
+ * 3 bucket offsets(u32) 4 keys after pass 1 5 keys after pass 2.  Returns the
+ * number of ELEMENTS copied (of the element type above). */
+int64_t kr_debug_fetch(kr_ctx*, int genome_id, int what, void* out, size_t cap_bytes);
+int     kr_debug_info(kr_ctx*, int64_t* out8);  /* b, nbuckets, T, CAP, nwg, overflow segments, fallback launches, 0 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,216 @@
+"""ctypes binding of libkrisp_hip.so (include/krisp_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails this
+module raises.  The host layer never computes k-mers, sorts or intersects on
+the CPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkrisp_hip.so")
+
+CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
+RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
+
+SOFT_MAP, SOFT_OMIT = 0, 1
+STAGES = ["pack", "hist", "scan", "scatter1", "scatter2", "localsort", "fallback",
+          "intersect", "compact", "collect", "merge"]
+
+# every symbol include/krisp_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+SYMBOLS = [
+    ("kr_create", _P, [_c.c_int, _c.c_size_t]),
+    ("kr_destroy", None, [_P]),
+    ("kr_last_error", _c.c_char_p, [_P]),
+    ("kr_set_params", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_size_t]),
+    ("kr_genome_upload", _c.c_int, [_P, _c.c_int, _P, _c.c_size_t]),
+    ("kr_genome_sort", _c.c_int, [_P, _c.c_int]),
+    ("kr_genome_add", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
+    ("kr_genome_count", _c.c_int64, [_P, _c.c_int]),
+    ("kr_genome_fetch_keys", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
+    ("kr_genome_free", _c.c_int, [_P, _c.c_int]),
+    ("kr_intersect", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
+    ("kr_cands_count", _c.c_int64, [_P]),
+    ("kr_cands_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
+    ("kr_cands_load", _c.c_int64, [_P, _P, _c.c_size_t]),
+    ("kr_cands_merge", _c.c_int64, [_P, _P, _c.c_size_t, _c.c_int, _c.c_int]),
+    ("kr_collect", _c.c_int64, [_P, _P, _c.c_int]),
+    ("kr_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
+    ("kr_sync", _c.c_int, [_P]),
+    ("kr_timer_begin", _c.c_int, [_P]),
+    ("kr_timer_end_ms", _c.c_double, [_P]),
+    ("kr_stage_enable", _c.c_int, [_P, _c.c_int]),
+    ("kr_stage_reset", _c.c_int, [_P]),
+    ("kr_stage_ms", _c.c_double, [_P, _c.c_int]),
+    ("kr_stage_launches", _c.c_int64, [_P, _c.c_int]),
+    ("kr_debug_fetch", _c.c_int64, [_P, _c.c_int, _c.c_int, _P, _c.c_size_t]),
+    ("kr_debug_info", _c.c_int, [_P, _P]),
+]
+
+
+class KrispHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KrispHipError(
+            f"{LIB_PATH} is missing: build it with `python -m krisp_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """One GPU context (one HIP stream) -- thin object face of the C ABI."""
+
+    def __init__(self, device=0, hbm_budget=0):
+        self.lib = load()
+        self.ctx = self.lib.kr_create(device, hbm_budget)
+        if not self.ctx:
+            raise KrispHipError("kr_create failed: " + self.lib.kr_last_error(None).decode())
+        self.params = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.kr_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise KrispHipError(f"{what}: [{rc}] " + self.lib.kr_last_error(self.ctx).decode())
+        return rc
+
+    # ---- configuration
+    def set_params(self, L, D, R, omit_soft=False, max_bases=0):
+        self._check(self.lib.kr_set_params(self.ctx, L, D, R, SOFT_OMIT if omit_soft else SOFT_MAP,
+                                           max_bases), "kr_set_params")
+        self.params = (L, D, R)
+
+    # ---- genomes
+    def upload(self, gid, bases):
+        buf = np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else bases
+        self._check(self.lib.kr_genome_upload(self.ctx, gid, _ptr(buf) if len(buf) else None, len(buf)),
+                    "kr_genome_upload")
+
+    def sort(self, gid):
+        self._check(self.lib.kr_genome_sort(self.ctx, gid), "kr_genome_sort")
+
+    def add(self, gid, bases):
+        self.upload(gid, bases)
+        self.sort(gid)
+        return self.count(gid)
+
+    def count(self, gid):
+        return self._check(self.lib.kr_genome_count(self.ctx, gid), "kr_genome_count")
+
+    def keys(self, gid):
+        n = self.count(gid)
+        out = np.empty(max(n, 1), dtype=np.uint64)
+        self._check(self.lib.kr_genome_fetch_keys(self.ctx, gid, _ptr(out), n), "kr_genome_fetch_keys")
+        return out[:n]
+
+    def free(self, gid):
+        self._check(self.lib.kr_genome_free(self.ctx, gid), "kr_genome_free")
+
+    # ---- intersection
+    def intersect(self, gids, is_ingroup, apply_filter=True):
+        ids = np.asarray(gids, dtype=np.int32)
+        flags = np.asarray([1 if f else 0 for f in is_ingroup], dtype=np.uint8)
+        return self._check(self.lib.kr_intersect(self.ctx, _ptr(ids), len(ids), _ptr(flags),
+                                                 1 if apply_filter else 0), "kr_intersect")
+
+    def cands(self):
+        n = self._check(self.lib.kr_cands_count(self.ctx), "kr_cands_count")
+        out = np.empty(max(n, 1), dtype=CAND)
+        self._check(self.lib.kr_cands_fetch(self.ctx, _ptr(out), n), "kr_cands_fetch")
+        return out[:n]
+
+    def load_cands(self, cands):
+        cands = np.ascontiguousarray(cands, dtype=CAND)
+        return self._check(self.lib.kr_cands_load(self.ctx, _ptr(cands) if len(cands) else None, len(cands)),
+                           "kr_cands_load")
+
+    def merge_cands(self, other=None, apply_filter=False):
+        if other is None:
+            return self._check(self.lib.kr_cands_merge(self.ctx, None, 0, 0, 1 if apply_filter else 0),
+                               "kr_cands_merge")
+        other = np.ascontiguousarray(other, dtype=CAND)
+        return self._check(self.lib.kr_cands_merge(self.ctx, _ptr(other) if len(other) else None,
+                                                   len(other), 1, 1 if apply_filter else 0),
+                           "kr_cands_merge")
+
+    def collect(self, gids):
+        ids = np.asarray(gids, dtype=np.int32)
+        n = self._check(self.lib.kr_collect(self.ctx, _ptr(ids), len(ids)), "kr_collect")
+        out = np.empty(max(n, 1), dtype=RECORD)
+        self._check(self.lib.kr_fetch(self.ctx, _ptr(out), n), "kr_fetch")
+        return out[:n]
+
+    # ---- timing
+    def sync(self):
+        self._check(self.lib.kr_sync(self.ctx), "kr_sync")
+
+    def timer_begin(self):
+        self._check(self.lib.kr_timer_begin(self.ctx), "kr_timer_begin")
+
+    def timer_end_ms(self):
+        ms = self.lib.kr_timer_end_ms(self.ctx)
+        if ms < 0:
+            raise KrispHipError("kr_timer_end_ms failed")
+        return ms
+
+    def stage_enable(self, on=True):
+        self.lib.kr_stage_enable(self.ctx, 1 if on else 0)
+
+    def stage_reset(self):
+        self.lib.kr_stage_reset(self.ctx)
+
+    def stage_times(self):
+        return {name: (self.lib.kr_stage_ms(self.ctx, i), self.lib.kr_stage_launches(self.ctx, i))
+                for i, name in enumerate(STAGES)}
+
+    # ---- introspection (stage-level parity tests)
+    def debug_info(self):
+        o = np.zeros(8, dtype=np.int64)
+        self.lib.kr_debug_info(self.ctx, _ptr(o))
+        return dict(b=int(o[0]), nbuckets=int(o[1]), T=int(o[2]), CAP=int(o[3]), nwg=int(o[4]),
+                    overflow_segments=int(o[5]), fallback_launches=int(o[6]), hbm_bytes=int(o[7]))
+
+    def debug_fetch(self, gid, what, n_max):
+        dt = {0: np.uint64, 1: np.uint32, 2: np.uint32, 3: np.uint32, 4: np.uint64, 5: np.uint64}[what]
+        out = np.empty(max(n_max, 1), dtype=dt)
+        n = self._check(self.lib.kr_debug_fetch(self.ctx, gid, what, _ptr(out), out.nbytes), "kr_debug_fetch")
+        return out[:n]

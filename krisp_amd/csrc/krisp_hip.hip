@@ -1,0 +1,1294 @@
+// krisp_hip.hip -- hand-written HIP (gfx950 / MI355X) for krisp_fasta's hot path:
+// 2-bit pack -> both-strand keys -> MSD radix partition (LDS digit histograms,
+// per-workgroup private cursors) -> LDS bucket sort -> n-way intersection with
+// diagnostic-column masks -> candidate compaction -> record collection.
+// C ABI: include/krisp_hip.h (each entry point cites the reference seam it replaces).
+//
+// Integer / byte work, HBM-bound: no MFMA anywhere (DESIGN.md "kernels").
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "krisp_hip.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ----------------------------------------------------------------------------
+// geometry shared by every kernel
+// ----------------------------------------------------------------------------
+struct Geom {
+    int k, L, D, R;
+    int b;          // radix fan-out bits of the two MSD passes (8 .. 18)
+    int rb;         // 64 - b
+    int sR, sD;     // layout shifts: right part << sR (= 2D), diag part >> sD (= 2R)
+    u64 topmask;    // top 2k bits
+    u64 mL, mR, mD; // destination masks of left / right / diag in [left|right|diag]
+    u64 pmask;      // top 2(L+R) bits: the (left,right) prefix
+    int omit;       // soft-mask rule
+};
+
+#define NWG 256            // persistent workgroups of the histogram / pass-1 kernels (one per CU)
+#define BIG_T 1024         // threads of those workgroups
+#define LS_T 2048u         // local-sort chunk window (keys)
+#define LS_CAP 4096u       // local-sort capacity (keys in LDS)
+#define LS_THREADS 256
+#define LS_PER (LS_CAP / LS_THREADS)
+#define LS_NB 4096u        // sub-bins of the LDS bucket sort
+#define LS_BIN_LIMIT 48u   // a fuller sub-bin switches the chunk to the bitonic network
+#define OVF_MAX 4096       // oversized-bucket list capacity
+#define IS_SUB 2048u       // anchor sub-tile of the intersect kernel
+#define IS_THREADS 256
+#define HIST_BITS 15       // LDS histogram bits per sweep (128 KiB of u32 counters)
+
+__device__ __forceinline__ u64 layout_key(u64 w, const Geom& g) {
+    return (w & g.mL) | ((w << g.sR) & g.mR) | ((w >> g.sD) & g.mD);
+}
+
+// window j (0..31) of the 32 bases of word c0 (continuing into c1): both-strand keys
+__device__ __forceinline__ bool window_keys(u64 c0, u64 c1, u32 b0, u32 b1, int j, const Geom& g,
+                                            u64& kf, u64& kr) {
+    u64 x = j ? ((c0 << (2 * j)) | (c1 >> (64 - 2 * j))) : c0;
+    u32 bm = j ? ((b0 << j) | (b1 >> (32 - j))) : b0;
+    if ((bm >> (32 - g.k)) != 0) return false;
+    u64 wf = x & g.topmask;
+    u64 y = ~(x >> (64 - 2 * g.k));
+    y = __brevll(y);
+    y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+    u64 wr = y & g.topmask;
+    kf = layout_key(wf, g);
+    kr = layout_key(wr, g);
+    return true;
+}
+
+// ----------------------------------------------------------------------------
+// K1  ASCII -> 2-bit codes (32 bases / u64, MSB first) + bad bits (32 / u32, MSB first)
+// ----------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t* __restrict__ bases, u64 n, u64* __restrict__ codes,
+                       u32* __restrict__ bad, u64 nwords_padded, int omit) {
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; w < nwords_padded; w += stride) {
+        u64 base = w * 32;
+        u64 c = 0;
+        u32 bd = 0;
+        if (base + 32 <= n) {
+            const uint4* p = reinterpret_cast<const uint4*>(bases + base);
+            uint4 v0 = p[0], v1 = p[1];
+            u32 wd[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    u32 ch = (wd[q] >> (8 * r)) & 0xFF;
+                    u32 up = ch & 0xDF;
+                    u32 code = (up >> 1) & 3;
+                    code ^= code >> 1;
+                    bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+                    if (omit) ok = ok & (ch == up);
+                    c = (c << 2) | (ok ? code : 0);
+                    bd = (bd << 1) | (ok ? 0u : 1u);
+                }
+            }
+        } else {
+            for (int q = 0; q < 32; q++) {
+                u32 code = 0;
+                bool ok = false;
+                if (base + q < n) {
+                    u32 ch = bases[base + q];
+                    u32 up = ch & 0xDF;
+                    code = (up >> 1) & 3;
+                    code ^= code >> 1;
+                    ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+                    if (omit) ok = ok & (ch == up);
+                }
+                c = (c << 2) | (ok ? code : 0);
+                bd = (bd << 1) | (ok ? 0u : 1u);
+            }
+        }
+        codes[w] = c;
+        bad[w] = bd;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K2  per-workgroup histogram of the top-b key bits, straight from the codes.
+// One sweep counts the keys whose top (b-15) bits equal `sweep` into a 2^15-bin
+// LDS histogram (plain u32 counters), then stores it to partial[wg][.].
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(BIG_T) void k_hist(const u64* __restrict__ codes,
+                                                const u32* __restrict__ bad, u64 nwords,
+                                                u32* __restrict__ partial, Geom g, int sweep) {
+    extern __shared__ __attribute__((aligned(16))) u32 lhist[];
+    const int hb = g.b < HIST_BITS ? g.b : HIST_BITS;
+    const u32 nbins = 1u << hb;
+    for (u32 i = threadIdx.x; i < nbins; i += BIG_T) lhist[i] = 0;
+    __syncthreads();
+    u64 wpw = (nwords + NWG - 1) / NWG;
+    u64 w0 = (u64)blockIdx.x * wpw;
+    u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
+    const int hi_bits = g.b - hb;   // bits selected by the sweep
+    for (u64 w = w0 + threadIdx.x; w < w1; w += BIG_T) {
+        u32 b0 = bad[w], b1 = bad[w + 1];
+        if (b0 == 0xFFFFFFFFu) continue;
+        u64 c0 = codes[w], c1 = codes[w + 1];
+#pragma unroll 4
+        for (int j = 0; j < 32; j++) {
+            u64 kf, kr;
+            if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
+            u32 df = (u32)(kf >> g.rb), dr = (u32)(kr >> g.rb);
+            if ((int)(df >> hb) == sweep || hi_bits == 0) atomicAdd(&lhist[df & (nbins - 1)], 1u);
+            if ((int)(dr >> hb) == sweep || hi_bits == 0) atomicAdd(&lhist[dr & (nbins - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    u32* row = partial + ((u64)blockIdx.x << g.b) + ((u64)sweep << hb);
+    for (u32 i = threadIdx.x; i < nbins; i += BIG_T) row[i] = lhist[i];
+}
+
+// ----------------------------------------------------------------------------
+// block-wide exclusive scan helper (blockDim.x <= 1024, multiple of 64)
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* lds_waves /* >= 17 u32 */, u32& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    u32 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) lds_waves[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int i = 0; i < nw; i++) { u32 t = lds_waves[i]; lds_waves[i] = run; run += t; }
+        lds_waves[16] = run;
+    }
+    __syncthreads();
+    u32 res = lds_waves[wave] + x - v;
+    total = lds_waves[16];
+    __syncthreads();
+    return res;
+}
+
+// ----------------------------------------------------------------------------
+// K2b  one workgroup per top digit d1: column sums -> global fine histogram,
+// row sums -> per-workgroup pass-1 cursor offsets (exclusive over workgroups).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(NWG) void k_reduce(const u32* __restrict__ partial, u32* __restrict__ hist,
+                                               u32* __restrict__ rowoff, u32* __restrict__ tot1, int b) {
+    __shared__ u32 waves[17];
+    const u32 nb2 = 1u << (b - 8);
+    const u32 d1 = blockIdx.x;
+    const u64 base = (u64)d1 * nb2;
+    for (u32 c = threadIdx.x; c < nb2; c += NWG) {
+        u32 s = 0;
+        for (u32 wg = 0; wg < NWG; wg++) s += partial[((u64)wg << b) + base + c];
+        hist[base + c] = s;
+    }
+    const u32* row = partial + ((u64)threadIdx.x << b) + base;
+    u32 s = 0;
+    for (u32 c = 0; c < nb2; c++) s += row[c];
+    u32 total;
+    u32 ex = block_excl_scan(s, waves, total);
+    rowoff[(u64)threadIdx.x * 256 + d1] = ex;
+    if (threadIdx.x == 0) tot1[d1] = total;
+}
+
+// ----------------------------------------------------------------------------
+// generic single-workgroup exclusive scan: out[0..n] (n+1 entries), out[n] = total
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+    __shared__ u32 waves[17];
+    const u32 per = (n + 1023) / 1024;
+    const u32 s0 = threadIdx.x * per;
+    const u32 s1 = s0 + per < n ? s0 + per : n;
+    u32 s = 0;
+    for (u32 i = s0; i < s1; i++) s += in[i];
+    u32 total;
+    u32 ex = block_excl_scan(s, waves, total);
+    for (u32 i = s0; i < s1; i++) { u32 v = in[i]; out[i] = ex; ex += v; }
+    if (threadIdx.x == 0) out[n] = total;
+}
+
+// ----------------------------------------------------------------------------
+// K3  pass 1: partition by the top 8 bits.  Same word ranges as k_hist, so the
+// workgroup's private cursors (base1[d] + rowoff[wg][d]) are exact: no global atomics.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(BIG_T) void k_scatter1(const u64* __restrict__ codes,
+                                                    const u32* __restrict__ bad, u64 nwords,
+                                                    const u32* __restrict__ base1,
+                                                    const u32* __restrict__ rowoff,
+                                                    u64* __restrict__ dst, Geom g) {
+    __shared__ u32 cur[256];
+    if (threadIdx.x < 256) cur[threadIdx.x] = base1[threadIdx.x] + rowoff[(u64)blockIdx.x * 256 + threadIdx.x];
+    __syncthreads();
+    u64 wpw = (nwords + NWG - 1) / NWG;
+    u64 w0 = (u64)blockIdx.x * wpw;
+    u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
+    for (u64 w = w0 + threadIdx.x; w < w1; w += BIG_T) {
+        u32 b0 = bad[w], b1 = bad[w + 1];
+        if (b0 == 0xFFFFFFFFu) continue;
+        u64 c0 = codes[w], c1 = codes[w + 1];
+#pragma unroll 4
+        for (int j = 0; j < 32; j++) {
+            u64 kf, kr;
+            if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
+            u32 sf = atomicAdd(&cur[(u32)(kf >> 56)], 1u);
+            dst[sf] = kf;
+            u32 sr = atomicAdd(&cur[(u32)(kr >> 56)], 1u);
+            dst[sr] = kr;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K4  pass 2: workgroup d1 owns pass-1 bucket d1 and splits it by the next b-8 bits
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(BIG_T) void k_scatter2(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                    const u32* __restrict__ off, int b) {
+    __shared__ u32 cur[1024];
+    const u32 nb2 = 1u << (b - 8);
+    const u32 f0 = blockIdx.x * nb2;
+    for (u32 i = threadIdx.x; i < nb2; i += BIG_T) cur[i] = off[f0 + i];
+    __syncthreads();
+    const u32 s = off[f0], e = off[f0 + nb2];
+    const int rb = 64 - b;
+    for (u32 i = s + threadIdx.x; i < e; i += BIG_T) {
+        u64 key = src[i];
+        u32 d2 = (u32)(key >> rb) & (nb2 - 1);
+        u32 slot = atomicAdd(&cur[d2], 1u);
+        dst[slot] = key;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K4b  chunk table: chunkstart[j] = first bucket whose start offset is >= j*T
+// (pre-filled with nbuckets).  Chunk j = buckets [chunkstart[j], chunkstart[j+1]).
+// ----------------------------------------------------------------------------
+__global__ void k_chunk_bounds(const u32* __restrict__ off, u32 nb, u32* __restrict__ chunkstart) {
+    u32 f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f > nb) return;
+    u32 cur = off[f];
+    u32 jlo = f == 0 ? 0 : off[f - 1] / LS_T + 1;
+    u32 jhi = cur / LS_T;
+    for (u32 j = jlo; j <= jhi; j++) chunkstart[j] = f;
+}
+
+// ----------------------------------------------------------------------------
+// K5  local sort of one chunk (<= LS_CAP keys) in LDS, in place in global memory:
+// count into 4096 order-preserving sub-bins (16-bit LDS counters), scan, place,
+// then rank every key inside its sub-bin by counting; a chunk with a crowded
+// sub-bin (duplicates, skew) runs a bitonic network instead.  A chunk that does
+// not fit reports its (single) oversized bucket for the global fallback.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ u32 cnt16_get(const u32* c, u32 i) {
+    u32 w = c[i >> 1];
+    return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys,
+                                                          const u32* __restrict__ off,
+                                                          const u32* __restrict__ chunkstart, int b,
+                                                          u32* __restrict__ ovf_count,
+                                                          uint2* __restrict__ ovf_list) {
+    __shared__ __attribute__((aligned(16))) u64 S[LS_CAP];
+    __shared__ u32 cnt[LS_NB / 2];
+    __shared__ u32 waves[17];
+    __shared__ u32 s_maxbin;
+    const u32 tid = threadIdx.x;
+    u32 lo = chunkstart[blockIdx.x], hi = chunkstart[blockIdx.x + 1];
+    if (lo >= hi) return;
+    u32 s = off[lo], e = off[hi];
+    u32 m = e - s;
+    if (m > LS_CAP) {
+        u32 last = hi - 1;
+        if (tid == 0) {
+            u32 idx = atomicAdd(ovf_count, 1u);
+            if (idx < OVF_MAX) ovf_list[idx] = make_uint2(off[last], e);
+        }
+        hi = last;
+        e = off[hi];
+        m = e - s;
+        if (m == 0 || lo >= hi) return;
+    }
+    const int rb = 64 - b;
+    const u32 nbk = hi - lo;
+    const int clog = nbk <= 1 ? 0 : 32 - __clz((int)(nbk - 1));
+    const int sh = rb + clog - 12;
+    const u64 keylo = (u64)lo << rb;
+
+    for (u32 i = tid; i < LS_NB / 2; i += LS_THREADS) cnt[i] = 0;
+    if (tid == 0) s_maxbin = 0;
+    __syncthreads();
+
+    u64 key[LS_PER];
+    u32 sub[LS_PER], r[LS_PER];
+#pragma unroll
+    for (int i = 0; i < (int)LS_PER; i++) {
+        u32 p = tid + i * LS_THREADS;
+        if (p < m) {
+            key[i] = keys[s + p];
+            sub[i] = (u32)((key[i] - keylo) >> sh);
+            u32 old = atomicAdd(&cnt[sub[i] >> 1], (sub[i] & 1) ? 0x10000u : 1u);
+            r[i] = (sub[i] & 1) ? (old >> 16) : (old & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 4096 counters: thread t owns bins [16t, 16t+16) = 8 words
+    {
+        u32 w[8];
+        u32 sum = 0, mx = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            w[q] = cnt[tid * 8 + q];
+            u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
+            sum += a + c2;
+            mx = max(mx, max(a, c2));
+        }
+        if (mx > LS_BIN_LIMIT) atomicMax(&s_maxbin, mx);
+        u32 total;
+        u32 ex = block_excl_scan(sum, waves, total);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
+            u32 lo16 = ex;
+            ex += a;
+            u32 hi16 = ex;
+            ex += c2;
+            cnt[tid * 8 + q] = lo16 | (hi16 << 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (int)LS_PER; i++) {
+        u32 p = tid + i * LS_THREADS;
+        if (p < m) S[cnt16_get(cnt, sub[i]) + r[i]] = key[i];
+    }
+    __syncthreads();
+    if (s_maxbin <= LS_BIN_LIMIT) {
+#pragma unroll 2
+        for (int i = 0; i < (int)LS_PER; i++) {
+            u32 p = tid + i * LS_THREADS;
+            if (p < m) {
+                u64 kk = S[p];
+                u32 sb = (u32)((kk - keylo) >> sh);
+                u32 b0 = cnt16_get(cnt, sb);
+                u32 b1 = sb + 1 < LS_NB ? cnt16_get(cnt, sb + 1) : m;
+                u32 rank = b0;
+                for (u32 q = b0; q < b1; q++) {
+                    u64 kq = S[q];
+                    rank += (kq < kk) || (kq == kk && q < p);
+                }
+                keys[s + rank] = kk;
+            }
+        }
+    } else {
+        u32 np = 1;
+        while (np < m) np <<= 1;
+        for (u32 p = m + tid; p < np; p += LS_THREADS) S[p] = ~0ull;
+        __syncthreads();
+        for (u32 kk = 2; kk <= np; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 t = tid; t < np / 2; t += LS_THREADS) {
+                    u32 i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    u32 i1 = i0 | j;
+                    bool up = (i0 & kk) == 0;
+                    u64 a = S[i0], c2 = S[i1];
+                    if ((a > c2) == up) { S[i0] = c2; S[i1] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (u32 p = tid; p < m; p += LS_THREADS) keys[s + p] = S[p];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Kb  one (k, j) stage of an all-ascending bitonic network over arbitrary-length
+// segments (flip on the first step of a merge, disperse after): the robust
+// fallback for buckets that do not fit the LDS sort.  grid.y = segment.
+// ----------------------------------------------------------------------------
+__global__ void k_bitonic_stage(u64* __restrict__ keys, const uint2* __restrict__ segs, u32 kk, u32 j,
+                                int flip) {
+    uint2 sg = segs[blockIdx.y];
+    u32 n = sg.y - sg.x;
+    u64* a = keys + sg.x;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        u32 p = flip ? (i ^ (kk - 1)) : (i ^ j);
+        if (p > i && p < n) {
+            u64 x = a[i], y = a[p];
+            if (x > y) { a[i] = y; a[p] = x; }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// ordered compaction inside a workgroup: position of this thread's flagged item
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ u32 block_compact(bool flag, u32* lds_waves, u32& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    u64 mask = __ballot(flag);
+    u32 pos = __popcll(mask & ((1ull << lane) - 1));
+    if (lane == 0) lds_waves[wave] = __popcll(mask);
+    __syncthreads();
+    u32 basev = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+        u32 t = lds_waves[i];
+        if (i < wave) basev += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return basev + pos;
+}
+
+__device__ __forceinline__ u64 diag_mask(u64 key, int LR, int D) {
+    u64 m = 0;
+    for (int c = 0; c < D; c++) {
+        u32 bb = (u32)(key >> (62 - 2 * (LR + c))) & 3u;
+        m |= 1ull << (4 * c + bb);
+    }
+    return m;
+}
+
+__device__ __forceinline__ bool passes_filter(u64 im, u64 om, int D) {
+    u64 x = im & om;
+    for (int c = 0; c < D; c++)
+        if (((x >> (4 * c)) & 15ull) == 0) return true;
+    return false;
+}
+
+// ----------------------------------------------------------------------------
+// K6  n-way intersection.  One workgroup per chunk of the anchor genome: the
+// distinct (left,right) prefixes of the chunk go to LDS; every genome (the
+// anchor included) streams its keys of the same bucket range past them
+// (binary search in LDS), OR-ing a presence bit and the diagnostic-column masks.
+// Survivors are written in order to tmp[anchor offset ...]; chunkcnt[j] = count.
+// ----------------------------------------------------------------------------
+#define MAXG 32
+struct IsectArgs {
+    const u64* keys[MAXG];
+    const u32* off[MAXG];
+    u32 ingroup_bits;
+    int n;
+    int anchor;
+    const u32* chunkstart;
+    kr_cand* tmp;
+    u32* chunkcnt;
+    int apply_filter;
+};
+
+__global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
+    __shared__ __attribute__((aligned(16))) u64 heads[IS_SUB];
+    __shared__ __attribute__((aligned(16))) u64 inm[IS_SUB];
+    __shared__ __attribute__((aligned(16))) u64 outm[IS_SUB];
+    __shared__ u32 present[IS_SUB];
+    __shared__ u32 waves[17];
+    const u32 tid = threadIdx.x;
+    const u32 lo = a.chunkstart[blockIdx.x], hi = a.chunkstart[blockIdx.x + 1];
+    if (lo >= hi) {
+        if (tid == 0) a.chunkcnt[blockIdx.x] = 0;
+        return;
+    }
+    const u64* KA = a.keys[a.anchor];
+    const u32 sa = a.off[a.anchor][lo], ea = a.off[a.anchor][hi];
+    const u32 full = a.n >= 32 ? 0xFFFFFFFFu : ((1u << a.n) - 1);
+    const int LR = g.L + g.R;
+    u32 nout = 0;
+    for (u32 sub = sa; sub < ea; sub += IS_SUB) {
+        const u32 cnt = min(IS_SUB, ea - sub);
+        // distinct prefixes of the sub-tile, in order
+        u32 nheads = 0;
+        for (u32 i0 = 0; i0 < cnt; i0 += IS_THREADS) {
+            u32 p = i0 + tid;
+            bool ishead = false;
+            u64 pre = 0;
+            if (p < cnt) {
+                u32 gi = sub + p;
+                pre = KA[gi] & g.pmask;
+                ishead = (gi == 0) || ((KA[gi - 1] & g.pmask) != pre);
+            }
+            u32 tot;
+            u32 pos = block_compact(ishead, waves, tot);
+            if (ishead) heads[nheads + pos] = pre;
+            nheads += tot;
+        }
+        __syncthreads();
+        if (nheads == 0) continue;
+        for (u32 h = tid; h < nheads; h += IS_THREADS) { present[h] = 0; inm[h] = 0; outm[h] = 0; }
+        __syncthreads();
+        const u64 first = heads[0], last = heads[nheads - 1];
+        const u32 fl = (u32)(first >> g.rb);
+        const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
+        for (int gi = 0; gi < a.n; gi++) {
+            const u64* K = a.keys[gi];
+            const u32 s = a.off[gi][fl], e = a.off[gi][fh];
+            const bool ing = (a.ingroup_bits >> gi) & 1;
+            for (u32 i = s + tid; i < e; i += IS_THREADS) {
+                u64 key = K[i];
+                u64 pre = key & g.pmask;
+                if (pre < first || pre > last) continue;
+                u32 l = 0, r = nheads;
+                while (l < r) {
+                    u32 mid = (l + r) >> 1;
+                    if (heads[mid] < pre) l = mid + 1; else r = mid;
+                }
+                if (l < nheads && heads[l] == pre) {
+                    atomicOr(&present[l], 1u << gi);
+                    if (g.D > 0) {
+                        u64 dm = diag_mask(key, LR, g.D);
+                        atomicOr((u64*)(ing ? &inm[l] : &outm[l]), dm);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 i0 = 0; i0 < nheads; i0 += IS_THREADS) {
+            u32 h = i0 + tid;
+            bool ok = false;
+            if (h < nheads) {
+                ok = present[h] == full;
+                if (ok && a.apply_filter && g.D > 0) ok = passes_filter(inm[h], outm[h], g.D);
+            }
+            u32 tot;
+            u32 pos = block_compact(ok, waves, tot);
+            if (ok) {
+                kr_cand c;
+                c.prefix = heads[h];
+                c.in_mask = inm[h];
+                c.out_mask = outm[h];
+                a.tmp[(u64)sa + nout + pos] = c;
+            }
+            nout += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.chunkcnt[blockIdx.x] = nout;
+}
+
+// K6b  dense, ordered candidate list from the per-chunk runs
+__global__ void k_gather_cands(const kr_cand* __restrict__ tmp, const u32* __restrict__ chunkstart,
+                               const u32* __restrict__ offA, const u32* __restrict__ chunkcnt,
+                               const u32* __restrict__ chunkpos, kr_cand* __restrict__ out) {
+    u32 n = chunkcnt[blockIdx.x];
+    if (n == 0) return;
+    u64 src = offA[chunkstart[blockIdx.x]];
+    u32 dst = chunkpos[blockIdx.x];
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[dst + i] = tmp[src + i];
+}
+
+// ----------------------------------------------------------------------------
+// K7  records of every candidate in one genome: distinct keys + multiplicities
+// ----------------------------------------------------------------------------
+__global__ void k_collect(const kr_cand* __restrict__ cands, u32 ncand, const u64* __restrict__ K,
+                          const u32* __restrict__ off, Geom g, u32 genome_id, kr_record* __restrict__ out,
+                          u64 cap, u64* __restrict__ nrec) {
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncand) return;
+    u64 pre = cands[c].prefix;
+    u32 f = (u32)(pre >> g.rb);
+    u32 f2 = (u32)((pre | ~g.pmask) >> g.rb) + 1;
+    u32 l = off[f], r = off[f2];
+    const u32 e = r;
+    while (l < r) {
+        u32 mid = l + ((r - l) >> 1);
+        if (K[mid] < pre) l = mid + 1; else r = mid;
+    }
+    u32 i = l;
+    while (i < e && (K[i] & g.pmask) == pre) {
+        u64 key = K[i];
+        u32 cnt = 1;
+        while (i + cnt < e && K[i + cnt] == key) cnt++;
+        u64 idx = atomicAdd(nrec, 1ull);
+        if (out && idx < cap) {
+            kr_record rec;
+            rec.key = key;
+            rec.genome = genome_id;
+            rec.count = cnt;
+            out[idx] = rec;
+        }
+        i += cnt;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K8  candidate list (x) candidate list, and/or the diagnostic filter
+// ----------------------------------------------------------------------------
+__global__ void k_cands_flag(kr_cand* __restrict__ cur, u32 n, const kr_cand* __restrict__ other, u32 m,
+                             int have_other, int apply_filter, int D, u32* __restrict__ flags,
+                             u32* __restrict__ blockcnt) {
+    __shared__ u32 waves[17];
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        kr_cand c = cur[i];
+        keep = true;
+        if (have_other) {
+            u32 l = 0, r = m;
+            while (l < r) {
+                u32 mid = l + ((r - l) >> 1);
+                if (other[mid].prefix < c.prefix) l = mid + 1; else r = mid;
+            }
+            if (l < m && other[l].prefix == c.prefix) {
+                c.in_mask |= other[l].in_mask;
+                c.out_mask |= other[l].out_mask;
+                cur[i] = c;
+            } else {
+                keep = false;
+            }
+        }
+        if (keep && apply_filter && D > 0) keep = passes_filter(c.in_mask, c.out_mask, D);
+        flags[i] = keep ? 1u : 0u;
+    }
+    u32 tot;
+    block_compact(keep, waves, tot);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;
+}
+
+__global__ void k_cands_compact(const kr_cand* __restrict__ cur, u32 n, const u32* __restrict__ flags,
+                                const u32* __restrict__ blockpos, kr_cand* __restrict__ out) {
+    __shared__ u32 waves[17];
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = i < n && flags[i] != 0;
+    u32 tot;
+    u32 pos = block_compact(keep, waves, tot);
+    if (keep) out[blockpos[blockIdx.x] + pos] = cur[i];
+}
+
+// ============================================================================
+// host side
+// ============================================================================
+static thread_local std::string g_last_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Genome {
+    int id = -1;
+    size_t n_bases = 0;
+    u64 nwords = 0;       // ceil(n/32)
+    u64 nmax = 0;         // upper bound of the key count
+    DevBuf bases, keys, off, chunkstart;
+    u32 nchunks = 0;
+    bool uploaded = false, sorted = false, finalized = false;
+    int64_t count = -1;
+    u32 ovf = 0;
+};
+
+struct kr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t budget = 0, used = 0;
+    bool have_params = false;
+    Geom g{};
+    size_t max_bases = 0;
+    std::map<int, Genome> genomes;
+    // scratch shared by all genome sorts
+    DevBuf codes, bad, partial, hist, rowoff, tot1, base1, tmpkeys, ovf_count, ovf_list;
+    // candidates / records
+    DevBuf candA, candB, chunkcnt, chunkpos, flags, blockcnt, blockpos, other, records, nrec;
+    int64_t ncand = -1;
+    int64_t nrecords = 0;
+    std::string err;
+    // timers
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool stage_on = false;
+    struct Pair { hipEvent_t a, b; int stage; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double stage_ms[KR_ST_COUNT] = {0};
+    int64_t stage_n[KR_ST_COUNT] = {0};
+    int64_t fallback_launches = 0, overflow_segments = 0;
+};
+
+static int fail(kr_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail((c), KR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+static int ensure(kr_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes < 16) bytes = 16;
+    if (b.bytes >= bytes) return KR_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(b.p);
+        c->used -= b.bytes;
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (c->budget && c->used + bytes > c->budget)
+        return fail(c, KR_ERR_CAPACITY, "hbm budget exceeded: need %zu more bytes, %zu of %zu in use", bytes,
+                    c->used, c->budget);
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    c->used += bytes;
+    return KR_OK;
+}
+
+static void release(kr_ctx* c, DevBuf& b) {
+    if (b.p) {
+        (void)hipFree(b.p);
+        c->used -= b.bytes;
+    }
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+struct StageScope {
+    kr_ctx* c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(kr_ctx* c_, int st) : c(c_), stage(st) {
+        c->stage_n[st]++;
+        if (!c->stage_on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~StageScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, stage});
+    }
+};
+
+static void resolve_stages(kr_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0;
+        (void)hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->stage_ms[p.stage] += ms;
+        c->pool.push_back(p.a);
+        c->pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+extern "C" {
+
+const char* kr_last_error(kr_ctx* c) { return c ? c->err.c_str() : g_last_error.c_str(); }
+
+kr_ctx* kr_create(int device, size_t hbm_budget_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_last_error = "no HIP device visible";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        g_last_error = "device index out of range";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_last_error = "hipSetDevice failed";
+        return nullptr;
+    }
+    kr_ctx* c = new kr_ctx();
+    c->device = device;
+    c->budget = hbm_budget_bytes;
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->t0) != hipSuccess ||
+        hipEventCreate(&c->t1) != hipSuccess) {
+        g_last_error = "stream / event creation failed";
+        delete c;
+        return nullptr;
+    }
+    (void)hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 4u << HIST_BITS);
+    return c;
+}
+
+void kr_destroy(kr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    resolve_stages(c);
+    for (auto& kv : c->genomes) {
+        release(c, kv.second.bases);
+        release(c, kv.second.keys);
+        release(c, kv.second.off);
+        release(c, kv.second.chunkstart);
+    }
+    DevBuf* all[] = {&c->codes, &c->bad, &c->partial, &c->hist, &c->rowoff, &c->tot1, &c->base1,
+                     &c->tmpkeys, &c->ovf_count, &c->ovf_list, &c->candA, &c->candB, &c->chunkcnt,
+                     &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec};
+    for (DevBuf* b : all) release(c, *b);
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->t0);
+    (void)hipEventDestroy(c->t1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static u64 topbits(int nbits) { return nbits <= 0 ? 0ull : (nbits >= 64 ? ~0ull : (~0ull << (64 - nbits))); }
+
+int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_bases) {
+    if (!c) return KR_ERR_PARAM;
+    const int k = L + D + R;
+    if (L < 0 || D < 0 || R < 0 || k < 1 || k > 32)
+        return fail(c, KR_ERR_PARAM, "need 1 <= L+D+R <= 32 on the packed path (got %d/%d/%d)", L, D, R);
+    if (D > 16) return fail(c, KR_ERR_PARAM, "diagnostic length %d > 16 unsupported by the mask format", D);
+    if (softmask_mode != KR_SOFT_MAP && softmask_mode != KR_SOFT_OMIT)
+        return fail(c, KR_ERR_PARAM, "unknown softmask mode %d", softmask_mode);
+    if (!c->genomes.empty()) return fail(c, KR_ERR_STATE, "kr_set_params after genomes were uploaded");
+    if (max_bases >= (1ull << 31)) return fail(c, KR_ERR_PARAM, "genomes of >= 2^31 bases need the chunked path");
+    Geom g{};
+    g.k = k; g.L = L; g.D = D; g.R = R;
+    g.sR = 2 * D;
+    g.sD = 2 * R;
+    g.topmask = topbits(2 * k);
+    g.mL = topbits(2 * L);
+    g.mR = topbits(2 * (L + R)) & ~g.mL;
+    g.mD = topbits(2 * k) & ~topbits(2 * (L + R));
+    g.pmask = topbits(2 * (L + R));
+    g.omit = softmask_mode == KR_SOFT_OMIT;
+    // fan-out: average fine bucket of ~1400 keys or fewer, 8 <= b <= 18
+    u64 nmax = 2 * (u64)max_bases;
+    int b = 8;
+    while (b < 18 && (nmax >> b) > 1400) b++;
+    g.b = b;
+    g.rb = 64 - b;
+    c->g = g;
+    c->max_bases = max_bases;
+    c->have_params = true;
+    return KR_OK;
+}
+
+int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
+    if (!c || !c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
+    if (n > c->max_bases) return fail(c, KR_ERR_PARAM, "genome of %zu bases exceeds max_bases %zu", n, c->max_bases);
+    HIPCHK(c, hipSetDevice(c->device));
+    Genome& G = c->genomes[id];
+    G.id = id;
+    G.n_bases = n;
+    G.nwords = (n + 31) / 32;
+    G.nmax = 2 * (u64)n;
+    G.sorted = G.finalized = false;
+    G.count = -1;
+    const u32 nb = 1u << c->g.b;
+    G.nchunks = (u32)(G.nmax / LS_T) + 1;
+    int rc;
+    if ((rc = ensure(c, G.bases, n + 64))) return rc;
+    if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
+    if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
+    if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
+    // shared scratch sized for the largest genome
+    const u64 mw = (c->max_bases + 31) / 32 + 4;
+    if ((rc = ensure(c, c->codes, mw * 8))) return rc;
+    if ((rc = ensure(c, c->bad, mw * 4))) return rc;
+    if ((rc = ensure(c, c->partial, (size_t)NWG * nb * 4))) return rc;
+    if ((rc = ensure(c, c->hist, (size_t)nb * 4))) return rc;
+    if ((rc = ensure(c, c->rowoff, (size_t)NWG * 256 * 4))) return rc;
+    if ((rc = ensure(c, c->tot1, 256 * 4))) return rc;
+    if ((rc = ensure(c, c->base1, 257 * 4))) return rc;
+    if ((rc = ensure(c, c->tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
+    if ((rc = ensure(c, c->ovf_count, 16))) return rc;
+    if ((rc = ensure(c, c->ovf_list, (size_t)OVF_MAX * 8))) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    G.uploaded = true;
+    return KR_OK;
+}
+
+int kr_genome_sort(kr_ctx* c, int id) {
+    if (!c) return KR_ERR_PARAM;
+    auto it = c->genomes.find(id);
+    if (it == c->genomes.end() || !it->second.uploaded) return fail(c, KR_ERR_STATE, "genome %d not uploaded", id);
+    HIPCHK(c, hipSetDevice(c->device));
+    Genome& G = it->second;
+    const Geom g = c->g;
+    const u32 nb = 1u << g.b;
+    hipStream_t st = c->stream;
+    u64* codes = (u64*)c->codes.p;
+    u32* bad = (u32*)c->bad.p;
+    const u64 nwp = G.nwords + 2;   // two pad words (all bad) so window j may read word w+1
+    {
+        StageScope sc(c, KR_ST_PACK);
+        u32 grid = (u32)std::min<u64>((nwp + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, st, (const uint8_t*)G.bases.p, (u64)G.n_bases, codes,
+                           bad, nwp, g.omit);
+    }
+    {
+        StageScope sc(c, KR_ST_HIST);
+        const int hb = g.b < HIST_BITS ? g.b : HIST_BITS;
+        const int sweeps = 1 << (g.b - hb);
+        for (int s = 0; s < sweeps; s++)
+            hipLaunchKernelGGL(k_hist, dim3(NWG), dim3(BIG_T), 4u << hb, st, (const u64*)codes, (const u32*)bad,
+                               G.nwords, (u32*)c->partial.p, g, s);
+    }
+    {
+        StageScope sc(c, KR_ST_SCAN);
+        hipLaunchKernelGGL(k_reduce, dim3(256), dim3(NWG), 0, st, (const u32*)c->partial.p, (u32*)c->hist.p,
+                           (u32*)c->rowoff.p, (u32*)c->tot1.p, g.b);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->tot1.p, (u32*)c->base1.p, 256u);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->hist.p, (u32*)G.off.p, nb);
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
+        hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
+                           (u32*)G.chunkstart.p);
+    }
+    u64* pass1_dst = g.b > 8 ? (u64*)c->tmpkeys.p : (u64*)G.keys.p;
+    {
+        StageScope sc(c, KR_ST_SCATTER1);
+        hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(BIG_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                           (const u32*)c->base1.p, (const u32*)c->rowoff.p, pass1_dst, g);
+    }
+    if (g.b > 8) {
+        StageScope sc(c, KR_ST_SCATTER2);
+        hipLaunchKernelGGL(k_scatter2, dim3(256), dim3(BIG_T), 0, st, (const u64*)c->tmpkeys.p, (u64*)G.keys.p,
+                           (const u32*)G.off.p, g.b);
+    }
+    {
+        StageScope sc(c, KR_ST_LOCALSORT);
+        HIPCHK(c, hipMemsetAsync(c->ovf_count.p, 0, 16, st));
+        hipLaunchKernelGGL(k_localsort, dim3(G.nchunks), dim3(LS_THREADS), 0, st, (u64*)G.keys.p,
+                           (const u32*)G.off.p, (const u32*)G.chunkstart.p, g.b, (u32*)c->ovf_count.p,
+                           (uint2*)c->ovf_list.p);
+    }
+    // The oversized-bucket list is shared scratch: resolve it before the next genome reuses it.
+    // The check costs one 4-byte D2H + sync per genome; the bitonic fallback only runs when needed.
+    u32 novf = 0;
+    HIPCHK(c, hipMemcpyAsync(&novf, c->ovf_count.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    G.ovf = novf;
+    if (novf) {
+        StageScope sc(c, KR_ST_FALLBACK);
+        std::vector<uint2> segs;
+        if (novf > OVF_MAX) {
+            u32 total = 0;
+            HIPCHK(c, hipMemcpy(&total, (u32*)G.off.p + nb, 4, hipMemcpyDeviceToHost));
+            segs.push_back(make_uint2(0, total));
+            HIPCHK(c, hipMemcpy(c->ovf_list.p, segs.data(), 8, hipMemcpyHostToDevice));
+        } else {
+            segs.resize(novf);
+            HIPCHK(c, hipMemcpy(segs.data(), c->ovf_list.p, (size_t)novf * 8, hipMemcpyDeviceToHost));
+        }
+        u32 maxlen = 0;
+        for (auto& s : segs) maxlen = std::max(maxlen, s.y - s.x);
+        c->overflow_segments += (int64_t)segs.size();
+        dim3 grid(std::min<u32>((maxlen + 255) / 256, 65535), (u32)segs.size());
+        for (u64 kk = 2; kk < 2ull * maxlen; kk <<= 1) {
+            for (u64 j = kk >> 1; j > 0; j >>= 1) {
+                hipLaunchKernelGGL(k_bitonic_stage, grid, dim3(256), 0, st, (u64*)G.keys.p,
+                                   (const uint2*)c->ovf_list.p, (u32)kk, (u32)j, j == (kk >> 1) ? 1 : 0);
+                c->fallback_launches++;
+            }
+        }
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    G.sorted = true;
+    G.finalized = true;
+    return KR_OK;
+}
+
+int64_t kr_genome_count(kr_ctx* c, int id) {
+    if (!c) return KR_ERR_PARAM;
+    auto it = c->genomes.find(id);
+    if (it == c->genomes.end() || !it->second.sorted) return fail(c, KR_ERR_STATE, "genome %d not sorted", id);
+    Genome& G = it->second;
+    if (G.count < 0) {
+        u32 total = 0;
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMemcpyAsync(&total, (u32*)G.off.p + (1u << c->g.b), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        G.count = total;
+    }
+    return G.count;
+}
+
+int64_t kr_genome_add(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
+    int rc = kr_genome_upload(c, id, bases, n);
+    if (rc) return rc;
+    rc = kr_genome_sort(c, id);
+    if (rc) return rc;
+    return kr_genome_count(c, id);
+}
+
+int64_t kr_genome_fetch_keys(kr_ctx* c, int id, uint64_t* out, size_t cap) {
+    int64_t n = kr_genome_count(c, id);
+    if (n < 0) return n;
+    if ((size_t)n > cap) return fail(c, KR_ERR_CAPACITY, "key buffer too small: %lld > %zu", (long long)n, cap);
+    Genome& G = c->genomes[id];
+    if (n) HIPCHK(c, hipMemcpy(out, G.keys.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int kr_genome_free(kr_ctx* c, int id) {
+    if (!c) return KR_ERR_PARAM;
+    auto it = c->genomes.find(id);
+    if (it == c->genomes.end()) return fail(c, KR_ERR_PARAM, "unknown genome %d", id);
+    (void)hipStreamSynchronize(c->stream);
+    release(c, it->second.bases);
+    release(c, it->second.keys);
+    release(c, it->second.off);
+    release(c, it->second.chunkstart);
+    c->genomes.erase(it);
+    return KR_OK;
+}
+
+int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int apply_filter) {
+    if (!c || n < 1) return fail(c, KR_ERR_PARAM, "kr_intersect: need at least one genome");
+    if (n > MAXG) return fail(c, KR_ERR_PARAM, "kr_intersect: at most %d genomes per call (cascade with kr_cands_merge)", MAXG);
+    HIPCHK(c, hipSetDevice(c->device));
+    IsectArgs a{};
+    a.n = n;
+    a.ingroup_bits = 0;
+    a.apply_filter = apply_filter ? 1 : 0;
+    int anchor = 0;
+    u64 best = ~0ull;
+    std::vector<Genome*> gs;
+    for (int i = 0; i < n; i++) {
+        auto it = c->genomes.find(ids[i]);
+        if (it == c->genomes.end() || !it->second.sorted) return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
+        Genome& G = it->second;
+        a.keys[i] = (const u64*)G.keys.p;
+        a.off[i] = (const u32*)G.off.p;
+        if (is_in[i]) a.ingroup_bits |= 1u << i;
+        if (G.nmax < best) { best = G.nmax; anchor = i; }
+        gs.push_back(&G);
+    }
+    Genome& A = *gs[anchor];
+    a.anchor = anchor;
+    a.chunkstart = (const u32*)A.chunkstart.p;
+    int rc;
+    if ((rc = ensure(c, c->candA, (A.nmax + 2) * sizeof(kr_cand)))) return rc;
+    if ((rc = ensure(c, c->candB, (A.nmax + 2) * sizeof(kr_cand)))) return rc;
+    if ((rc = ensure(c, c->chunkcnt, ((size_t)A.nchunks + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->chunkpos, ((size_t)A.nchunks + 2) * 4))) return rc;
+    a.tmp = (kr_cand*)c->candA.p;
+    a.chunkcnt = (u32*)c->chunkcnt.p;
+    hipStream_t st = c->stream;
+    {
+        StageScope sc(c, KR_ST_INTERSECT);
+        hipLaunchKernelGGL(k_intersect, dim3(A.nchunks), dim3(IS_THREADS), 0, st, a, c->g);
+    }
+    {
+        StageScope sc(c, KR_ST_COMPACT);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->chunkcnt.p, (u32*)c->chunkpos.p, A.nchunks);
+        hipLaunchKernelGGL(k_gather_cands, dim3(A.nchunks), dim3(64), 0, st, (const kr_cand*)c->candA.p,
+                           (const u32*)A.chunkstart.p, (const u32*)A.off.p, (const u32*)c->chunkcnt.p,
+                           (const u32*)c->chunkpos.p, (kr_cand*)c->candB.p);
+    }
+    u32 total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->chunkpos.p + A.nchunks, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    c->ncand = total;
+    return total;
+}
+
+int64_t kr_cands_count(kr_ctx* c) { return c ? c->ncand : KR_ERR_PARAM; }
+
+int64_t kr_cands_fetch(kr_ctx* c, kr_cand* out, size_t cap) {
+    if (!c || c->ncand < 0) return fail(c, KR_ERR_STATE, "no candidate set");
+    if ((size_t)c->ncand > cap) return fail(c, KR_ERR_CAPACITY, "candidate buffer too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->ncand) HIPCHK(c, hipMemcpy(out, c->candB.p, (size_t)c->ncand * sizeof(kr_cand), hipMemcpyDeviceToHost));
+    return c->ncand;
+}
+
+int64_t kr_cands_load(kr_ctx* c, const kr_cand* cands, size_t n) {
+    if (!c) return KR_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->candB, (n + 2) * sizeof(kr_cand)))) return rc;
+    if ((rc = ensure(c, c->candA, (n + 2) * sizeof(kr_cand)))) return rc;
+    if (n) HIPCHK(c, hipMemcpy(c->candB.p, cands, n * sizeof(kr_cand), hipMemcpyHostToDevice));
+    c->ncand = (int64_t)n;
+    return c->ncand;
+}
+
+int64_t kr_cands_merge(kr_ctx* c, const kr_cand* other, size_t m, int have_other, int apply_filter) {
+    if (!c || c->ncand < 0) return fail(c, KR_ERR_STATE, "no candidate set");
+    if (!c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const u32 n = (u32)c->ncand;
+    if (n == 0) return 0;
+    hipStream_t st = c->stream;
+    int rc;
+    const u32 nblk = (n + 255) / 256;
+    if ((rc = ensure(c, c->flags, (size_t)n * 4))) return rc;
+    if ((rc = ensure(c, c->blockcnt, ((size_t)nblk + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->blockpos, ((size_t)nblk + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->candA, ((size_t)n + 2) * sizeof(kr_cand)))) return rc;
+    if (have_other) {
+        if ((rc = ensure(c, c->other, (m + 2) * sizeof(kr_cand)))) return rc;
+        if (m) HIPCHK(c, hipMemcpyAsync(c->other.p, other, m * sizeof(kr_cand), hipMemcpyHostToDevice, st));
+    }
+    {
+        StageScope sc(c, KR_ST_MERGE);
+        hipLaunchKernelGGL(k_cands_flag, dim3(nblk), dim3(256), 0, st, (kr_cand*)c->candB.p, n,
+                           (const kr_cand*)c->other.p, (u32)m, have_other ? 1 : 0, apply_filter ? 1 : 0, c->g.D,
+                           (u32*)c->flags.p, (u32*)c->blockcnt.p);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->blockcnt.p, (u32*)c->blockpos.p, nblk);
+        hipLaunchKernelGGL(k_cands_compact, dim3(nblk), dim3(256), 0, st, (const kr_cand*)c->candB.p, n,
+                           (const u32*)c->flags.p, (const u32*)c->blockpos.p, (kr_cand*)c->candA.p);
+    }
+    u32 total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->blockpos.p + nblk, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    std::swap(c->candA, c->candB);
+    c->ncand = total;
+    return total;
+}
+
+int64_t kr_collect(kr_ctx* c, const int* ids, int n) {
+    if (!c || c->ncand < 0) return fail(c, KR_ERR_STATE, "no candidate set");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    int rc;
+    if ((rc = ensure(c, c->nrec, 16))) return rc;
+    const u32 nc = (u32)c->ncand;
+    c->nrecords = 0;
+    if (nc == 0 || n == 0) return 0;
+    for (int pass = 0; pass < 2; pass++) {
+        HIPCHK(c, hipMemsetAsync(c->nrec.p, 0, 16, st));
+        StageScope sc(c, KR_ST_COLLECT);
+        for (int i = 0; i < n; i++) {
+            auto it = c->genomes.find(ids[i]);
+            if (it == c->genomes.end() || !it->second.sorted)
+                return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
+            Genome& G = it->second;
+            hipLaunchKernelGGL(k_collect, dim3((nc + 127) / 128), dim3(128), 0, st, (const kr_cand*)c->candB.p, nc,
+                               (const u64*)G.keys.p, (const u32*)G.off.p, c->g, (u32)ids[i],
+                               pass ? (kr_record*)c->records.p : (kr_record*)nullptr,
+                               pass ? (u64)(c->records.bytes / sizeof(kr_record)) : 0ull, (u64*)c->nrec.p);
+        }
+        u64 total = 0;
+        HIPCHK(c, hipMemcpyAsync(&total, c->nrec.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+        c->nrecords = (int64_t)total;
+        if (pass == 0) {
+            if (total == 0) return 0;
+            if ((rc = ensure(c, c->records, (total + 2) * sizeof(kr_record)))) return rc;
+        }
+    }
+    return c->nrecords;
+}
+
+int64_t kr_fetch(kr_ctx* c, kr_record* out, size_t cap) {
+    if (!c) return KR_ERR_PARAM;
+    if ((size_t)c->nrecords > cap) return fail(c, KR_ERR_CAPACITY, "record buffer too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->nrecords)
+        HIPCHK(c, hipMemcpy(out, c->records.p, (size_t)c->nrecords * sizeof(kr_record), hipMemcpyDeviceToHost));
+    return c->nrecords;
+}
+
+int kr_sync(kr_ctx* c) {
+    if (!c) return KR_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return KR_OK;
+}
+
+int kr_timer_begin(kr_ctx* c) {
+    if (!c) return KR_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    return KR_OK;
+}
+
+double kr_timer_end_ms(kr_ctx* c) {
+    if (!c) return -1.0;
+    float ms = 0;
+    if (hipEventRecord(c->t1, c->stream) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(c->t1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, c->t0, c->t1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int kr_stage_enable(kr_ctx* c, int on) {
+    if (!c) return KR_ERR_PARAM;
+    c->stage_on = on != 0;
+    return KR_OK;
+}
+
+int kr_stage_reset(kr_ctx* c) {
+    if (!c) return KR_ERR_PARAM;
+    (void)hipStreamSynchronize(c->stream);
+    resolve_stages(c);
+    for (int i = 0; i < KR_ST_COUNT; i++) { c->stage_ms[i] = 0; c->stage_n[i] = 0; }
+    return KR_OK;
+}
+
+double kr_stage_ms(kr_ctx* c, int stage) {
+    if (!c || stage < 0 || stage >= KR_ST_COUNT) return -1.0;
+    (void)hipStreamSynchronize(c->stream);
+    resolve_stages(c);
+    return c->stage_ms[stage];
+}
+
+int64_t kr_stage_launches(kr_ctx* c, int stage) {
+    if (!c || stage < 0 || stage >= KR_ST_COUNT) return -1;
+    return c->stage_n[stage];
+}
+
+int64_t kr_debug_fetch(kr_ctx* c, int id, int what, void* out, size_t cap_bytes) {
+    if (!c) return KR_ERR_PARAM;
+    auto it = c->genomes.find(id);
+    if (it == c->genomes.end()) return fail(c, KR_ERR_PARAM, "unknown genome %d", id);
+    Genome& G = it->second;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u32 nb = 1u << c->g.b;
+    const void* src = nullptr;
+    size_t esz = 8, n = 0;
+    u32 total = 0;
+    HIPCHK(c, hipMemcpy(&total, (u32*)G.off.p + nb, 4, hipMemcpyDeviceToHost));
+    switch (what) {
+    case 0: src = c->codes.p; esz = 8; n = G.nwords + 2; break;
+    case 1: src = c->bad.p; esz = 4; n = G.nwords + 2; break;
+    case 2: src = c->hist.p; esz = 4; n = nb; break;
+    case 3: src = G.off.p; esz = 4; n = nb + 1; break;
+    case 4: src = c->g.b > 8 ? c->tmpkeys.p : G.keys.p; esz = 8; n = total; break;
+    case 5: src = G.keys.p; esz = 8; n = total; break;
+    default: return fail(c, KR_ERR_PARAM, "kr_debug_fetch: unknown selector %d", what);
+    }
+    if (n * esz > cap_bytes) return fail(c, KR_ERR_CAPACITY, "debug buffer too small");
+    if (n) HIPCHK(c, hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost));
+    return (int64_t)n;
+}
+
+int kr_debug_info(kr_ctx* c, int64_t* o) {
+    if (!c || !o) return KR_ERR_PARAM;
+    o[0] = c->g.b;
+    o[1] = 1ll << c->g.b;
+    o[2] = LS_T;
+    o[3] = LS_CAP;
+    o[4] = NWG;
+    o[5] = c->overflow_segments;
+    o[6] = c->fallback_launches;
+    o[7] = (int64_t)c->used;
+    return KR_OK;
+}
+
+}  // extern "C"

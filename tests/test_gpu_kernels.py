@@ -1,0 +1,175 @@
+"""GPU parity: libkrisp_hip.so (through the C ABI) against the packed-key oracle
+(oracle/kmer_oracle.c) on the same seeded inputs.  Bit-exact (integer keys)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    from krisp_amd import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def K():
+    from oracle import kmer_oracle
+    kmer_oracle.build()
+    return kmer_oracle
+
+
+def _rand_text(seed, n, alphabet=b"ACGT", records=3):
+    rng = np.random.default_rng(seed)
+    a = np.frombuffer(alphabet, dtype=np.uint8)
+    t = a[rng.integers(0, len(a), size=n)]
+    if records > 1 and n > records:
+        for p in rng.integers(0, n, size=records - 1):
+            t[p] = 10
+    return t
+
+
+def _check_sorted(N, K, text, L, D, R, omit=False, stages=False):
+    want = K.sorted_keys(text.tobytes(), L, D, R, omit=omit)
+    with N.Engine() as e:
+        e.set_params(L, D, R, omit_soft=omit, max_bases=len(text))
+        e.upload(0, text)
+        e.sort(0)
+        info = e.debug_info()
+        assert e.count(0) == len(want), info
+        if stages:
+            b = info["b"]
+            top = (want >> np.uint64(64 - b)).astype(np.int64)
+            hist = np.bincount(top, minlength=1 << b).astype(np.uint32)
+            got_hist = e.debug_fetch(0, 2, 1 << b)
+            assert np.array_equal(got_hist, hist), "fine histogram"
+            off = np.concatenate([[0], np.cumsum(hist)]).astype(np.uint32)
+            assert np.array_equal(e.debug_fetch(0, 3, (1 << b) + 1), off), "bucket offsets"
+            p1 = e.debug_fetch(0, 4, len(want) + 4)
+            assert len(p1) == len(want)
+            assert np.array_equal(np.sort(p1), want), "pass-1 output is a permutation of the keys"
+            d1 = (p1 >> np.uint64(56)).astype(np.int64)
+            assert np.all(np.diff(d1) >= 0), "pass-1 output partitioned by the top byte"
+        got = e.keys(0)
+        assert np.array_equal(got, want), info
+        return info
+
+
+def test_sort_random_genome_with_stages(N, K):
+    text = _rand_text(1, 300_000, b"ACGT" * 12 + b"acgtN", records=5)
+    info = _check_sorted(N, K, text, 25, 1, 2, stages=True)
+    assert info["overflow_segments"] == 0
+
+
+def test_sort_omit_soft(N, K):
+    text = _rand_text(2, 200_000, b"ACGT" * 12 + b"acgtNn", records=4)
+    _check_sorted(N, K, text, 25, 1, 2, omit=True, stages=True)
+
+
+@pytest.mark.parametrize("L,D,R", [(25, 1, 2), (28, 1, 2), (3, 1, 2), (15, 2, 15), (16, 0, 16),
+                                   (0, 2, 3), (3, 2, 0), (1, 0, 0), (10, 16, 6), (12, 4, 12)])
+def test_sort_geometries(N, K, L, D, R):
+    text = _rand_text(10 + L + D + R, 50_000, b"ACGT" * 10 + b"aN", records=3)
+    _check_sorted(N, K, text, L, D, R, stages=True)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 27, 28, 29, 31, 32, 33, 63, 64, 65, 100, 4095, 4097, 8193])
+def test_sort_tiny_inputs(N, K, n):
+    text = _rand_text(100 + n, n, b"ACGT", records=1)
+    _check_sorted(N, K, text, 25, 1, 2)
+
+
+def test_sort_all_invalid(N, K):
+    text = np.frombuffer(b"N" * 1000 + b"\n" + b"acgt" * 100, dtype=np.uint8)
+    _check_sorted(N, K, text, 5, 1, 2, omit=True)
+
+
+def test_sort_duplicates_use_bitonic_path(N, K):
+    # few distinct keys, many copies: crowded sub-bins inside the LDS sort
+    rng = np.random.default_rng(5)
+    unit = _rand_text(6, 97, b"ACGT", records=1)
+    text = np.concatenate([unit] * 40 + [_rand_text(7, 3000, b"ACGT", records=1)])
+    _check_sorted(N, K, text, 25, 1, 2)
+
+
+def test_sort_skewed_genome_overflow_fallback(N, K):
+    # 60 kbp of poly-A + a tandem repeat: one fine bucket far above the LDS capacity
+    rng = np.random.default_rng(8)
+    parts = [_rand_text(9, 400_000, b"ACGT", records=4),
+             np.frombuffer(b"A" * 60_000, dtype=np.uint8),
+             _rand_text(11, 100_000, b"ACGT", records=1),
+             np.frombuffer(b"ACACACACAC" * 3000, dtype=np.uint8)]
+    text = np.concatenate(parts)
+    info = _check_sorted(N, K, text, 25, 1, 2)
+    assert info["overflow_segments"] >= 1 and info["fallback_launches"] > 0
+
+
+def _family(seed, n, length, mu=0.01):
+    from krisp_amd import synth
+    return synth.family(seed, n // 2, n - n // 2, length, records=4, mu=mu, snp_every=2000)
+
+
+@pytest.mark.parametrize("L,D,R,length,n", [(25, 1, 2, 200_000, 4), (8, 1, 4, 20_000, 5),
+                                            (12, 4, 12, 100_000, 3), (14, 0, 14, 100_000, 4),
+                                            (3, 1, 0, 5_000, 2), (2, 1, 1, 3_000, 4)])
+def test_intersect_and_collect(N, K, L, D, R, length, n):
+    fam = _family(L + D + R, n, length)
+    flags = [f for _, f, _ in fam]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
+    with N.Engine() as e:
+        e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            assert e.add(i, t) == len(want_keys[i])
+        for filt in (False, True):
+            want = K.intersect(want_keys, flags, L, D, R, apply_filter=filt)
+            ncand = e.intersect(list(range(n)), flags, apply_filter=filt)
+            got = e.cands()
+            assert ncand == len(want)
+            assert np.array_equal(got["prefix"], want["prefix"])
+            assert np.array_equal(got["in_mask"], want["in_mask"])
+            assert np.array_equal(got["out_mask"], want["out_mask"])
+            recs = e.collect(list(range(n)))
+            wrec = K.collect(want_keys, want, L, D, R)
+            got_sorted = np.sort(recs, order=["key", "genome"])
+            want_sorted = np.sort(wrec, order=["key", "genome"])
+            assert np.array_equal(got_sorted, want_sorted)
+        # deferred filter == fused filter; list (x) list merge == n-way intersect
+        want_f = K.intersect(want_keys, flags, L, D, R, apply_filter=True)
+        e.intersect(list(range(n)), flags, apply_filter=False)
+        assert e.merge_cands(None, apply_filter=True) == len(want_f)
+        assert np.array_equal(e.cands()["prefix"], want_f["prefix"])
+        if n >= 4:
+            half = n // 2
+            e.intersect(list(range(half)), flags[:half], apply_filter=False)
+            a = e.cands().copy()
+            e.intersect(list(range(half, n)), flags[half:], apply_filter=False)
+            assert e.merge_cands(a, apply_filter=True) == len(want_f)
+            got = e.cands()
+            assert np.array_equal(got["prefix"], want_f["prefix"])
+            assert np.array_equal(got["in_mask"], want_f["in_mask"])
+            assert np.array_equal(got["out_mask"], want_f["out_mask"])
+
+
+def test_stage_timers_and_medium_size(N, K):
+    fam = _family(77, 4, 1_000_000)
+    flags = [f for _, f, _ in fam]
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=max(len(t) for _, _, t in fam))
+        e.stage_enable(True)
+        for i, (_, _, t) in enumerate(fam):
+            e.upload(i, t)
+        e.timer_begin()
+        for i in range(4):
+            e.sort(i)
+        ncand = e.intersect([0, 1, 2, 3], flags, apply_filter=True)
+        ms = e.timer_end_ms()
+        st = e.stage_times()
+        total = sum(e.count(i) for i in range(4))
+        print(f"\n4 x 1 Mbp: {total} k-mers in {ms:.3f} ms = {total / ms / 1e6:.2f} G k-mers/s; "
+              f"cands {ncand}; stages {st}; info {e.debug_info()}")
+        want_keys = [K.sorted_keys(t.tobytes(), 25, 1, 2) for _, _, t in fam]
+        want = K.intersect(want_keys, flags, 25, 1, 2, apply_filter=True)
+        assert ncand == len(want)
+        assert np.array_equal(e.cands()["prefix"], want["prefix"])
+        for i in range(4):
+            assert np.array_equal(e.keys(i), want_keys[i])
