@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s sorted + intersected (BASELINE.json metric) on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic genomes that are
+already resident in HBM as ASCII bases: per genome pack -> both-strand keys ->
+MSD radix partition -> LDS sort, then the n-way intersection + diagnostic
+filter.  At N = 1 the workload is BASELINE.json configs[1]: 4 synthetic 50 Mbp
+genomes (2 in / 2 out), k = 28 as 25/1/2.  At N > 1 every rank gets its own 4
+genomes of one 4N-genome family (weak scaling; SURVEY.md 8e, configs[3] style):
+sort + local intersect per GPU, then ONE exchange -- a binary-tree reduction of
+candidate lists over RCCL -- and the filter on rank 0.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MODEL_BYTES_PER_KMER = 136.5    # 0.5 + W + W + 2*W*P + W at W = 8, P = 7 (k = 28)
+
+# ALGORITHMIC bytes per k-mer record of each kernel stage (DESIGN.md "kernels"):
+# the stage's share of SURVEY 8(d)'s model -- bases in, key write, pass read+write, intersect read.
+STAGE_BYTES = {
+    "pack": 0.5 + 0.1875,           # 1 B/base in, 3 bits/base out; two records per base
+    "hist": 0.1875,                 # codes + bad bits in (per sweep)
+    "scatter1": 0.1875 + 8.0,       # codes in, one 8-byte key out
+    "scatter2": 16.0,               # key in, key out
+    "localsort": 16.0,              # key in, key out
+    "intersect": 8.0,               # every key of every genome read once
+}
+
+
+def make_genomes(config, rank, world, per_rank, length, independent=False):
+    from krisp_amd import synth
+    total = per_rank * world
+    n_in = total // 2
+    anc = None if independent else synth.ancestor(config, length)
+    out = []
+    for g in range(rank * per_rank, (rank + 1) * per_rank):
+        ing = g < n_in
+        codes = synth.genome_codes(config, g, length, ing, mu=0.01, snp_every=10000,
+                                   independent=independent, anc=anc)
+        out.append((g, ing, synth.codes_to_text(codes, records=16)))
+    return out
+
+
+def cpu_baseline(config, L, D, R, length):
+    """The packed-key C oracle (oracle/kmer_oracle.c, 1 thread) on a bounded sample
+    of the same workload: same generator and parameters, shorter genomes."""
+    from oracle import kmer_oracle as K
+    K.build()
+    fam = make_genomes(config, 0, 1, 4, length)
+    t0 = time.perf_counter()
+    keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
+    K.intersect(keys, [f for _, f, _ in fam], L, D, R, apply_filter=True)
+    dt = time.perf_counter() - t0
+    n = sum(len(k) for k in keys)
+    return {"value": n / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": f"4 x {length / 1e6:g} Mbp genomes of the same generator, {L}/{D}/{R}, "
+                      f"{n} k-mers in {dt:.1f} s (oracle/kmer_oracle.c: generate + LSD radix sort + "
+                      f"n-way intersect + filter)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--length", type=int, default=50_000_000, help="bases per genome (C2: 50 Mbp)")
+    ap.add_argument("--per-gpu", type=int, default=4, help="genomes per GPU")
+    ap.add_argument("--ldr", type=int, nargs=3, default=[25, 1, 2])
+    ap.add_argument("--independent", action="store_true", help="independent random genomes")
+    ap.add_argument("--cpu-length", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+
+    from krisp_amd import _native
+    dist = None
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        device = torch.device("cuda", local_rank)
+    from krisp_amd.distributed import tree_reduce_candidates
+
+    L, D, R = args.ldr
+    config = 2
+    genomes = make_genomes(config, rank, world, args.per_gpu, args.length, args.independent)
+    eng = _native.Engine(device=local_rank)
+    eng.set_params(L, D, R, omit_soft=False, max_bases=max(len(t) for _, _, t in genomes))
+    ids = []
+    for g, ing, text in genomes:
+        eng.upload(g, text)            # inputs resident in HBM before the timed region
+        ids.append(g)
+    flags = [ing for _, ing, _ in genomes]
+    del genomes
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def step():
+        for g in ids:
+            eng.sort(g)
+        if world == 1:
+            return eng.intersect(ids, flags, apply_filter=True)
+        eng.intersect(ids, flags, apply_filter=False)
+        return tree_reduce_candidates(eng, dist, rank, world, apply_filter=True, device=device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_stage_timers:
+        eng.stage_enable(True)
+        eng.stage_reset()
+    t0 = time.perf_counter()
+    ncand = 0
+    for _ in range(args.steps):
+        ncand = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = eng.stage_times() if not args.no_stage_timers else {}
+    kmers_local = sum(eng.count(g) for g in ids)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        k = torch.tensor([kmers_local], dtype=torch.int64, device=device)
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        kmers_total = int(k.item())
+    else:
+        kmers_total = kmers_local
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = kmers_total * args.steps / dt
+        # dominant kernel stage of this rank (HIP events on the engine's stream)
+        roof = None
+        if stages:
+            cand = {s: v for s, v in stages.items() if s in STAGE_BYTES and v[1] > 0}
+            dom = max(cand, key=lambda s: cand[s][0])
+            ms, launches = cand[dom]
+            avg_ms = ms / launches
+            # hist launches once per sweep, intersect once per step over all local genomes
+            per_launch = kmers_local if dom == "intersect" else kmers_local / len(ids)
+            achieved = STAGE_BYTES[dom] * per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get(dom)
+                except Exception:  # noqa: BLE001
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "bytes_per_kmer": STAGE_BYTES[dom], "kmers_per_launch": per_launch,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                    "pipeline_model_GBps": round(MODEL_BYTES_PER_KMER * value / world / 1e9, 1),
+                    "pipeline_model_frac": round(MODEL_BYTES_PER_KMER * value / world / 1e9 / HBM_PEAK_GBPS, 4),
+                    "stage_ms_per_step": {s: round(v[0] / args.steps, 4) for s, v in stages.items() if v[1]}}
+        out = {
+            "metric": "k-mers/s sorted+intersected at k=28", "value": value, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.per_gpu} synthetic {args.length / 1e6:g} Mbp random "
+                                   f"genomes per GPU (half in / half out over the {args.per_gpu * world}-genome "
+                                   f"family, mu=0.01, planted SNP / 10 kb), {L}/{D}/{R} spacer search",
+                       "kmers_per_step": kmers_total, "candidates": int(ncand),
+                       "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else " + tree-reduce of candidates")},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(config, L, D, R, args.cpu_length)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
