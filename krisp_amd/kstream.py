@@ -1,0 +1,265 @@
+"""`kstream` -- the reference's k-mer generator surface, MI355X-backed.
+
+Same constructor, iteration, call and write() contract as the reference class
+(kstream/kstream.py:122-428) and the same `kstream` command line
+(kstream.py:835-952).  The option combination krisp_fasta uses
+(krisp_fasta.py:21-43: kmers=k, complements, disallow="Nn", omitsoft|mapsoft,
+split=[L,-R], sort with sortcols=[0,2]) runs on the GPU through
+libkrisp_hip.so -- and ONLY there: no CPU path exists for it, a missing library
+raises.  Every other combination is outside the accelerated hot path
+ and is served by the plain host generator chain below.
+"""
+import argparse
+import itertools
+import sys
+
+import numpy as np
+
+from . import codec, fasta
+
+# kstream.py:11-18
+COMP_MAP = dict(zip("ATatGCgcRYryMKmkSWswBVbvDHdhNn", "TAtaCGcgYRyrKMkmSWswVBvbHDhdNn"))
+# kstream.py:21-42
+IUPAC_BASE = {"R": "AG", "Y": "CT", "S": "GC", "W": "AT", "K": "GT", "M": "AC",
+              "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT"}
+IUPAC_BASE.update({k.lower(): v.lower() for k, v in list(IUPAC_BASE.items())})
+
+_WRITE_CHUNK = 1 << 22      # keys decoded to text per chunk
+
+
+def _revcomp(s):
+    return "".join([COMP_MAP[c] for c in reversed(s)])   # KeyError as kstream.py:658
+
+
+class kstream:
+    def __init__(self, sequences=None, kmers=None, complements=False,
+                 canonicals=False, allow=None, disallow=None, omitsoft=False,
+                 mapsoft=False, expandiupac=False, split=None, sort=False,
+                 sortmem=None, sortcols=None, sortnp=1, parallel=1, *, device=0):
+        self.kmers = None
+        if kmers is not None:
+            self.kmers = [kmers] if isinstance(kmers, int) else list(kmers)
+        if omitsoft is True and mapsoft is True:
+            raise ValueError("can't omit and map soft masked nucleotides")
+        if complements is True and canonicals is True:
+            raise ValueError("canonicals conflicts with complements")
+        self.omitsoft = omitsoft is True
+        self.mapsoft = mapsoft is True
+        self.complements = complements is True
+        self.canonicals = canonicals is True
+        self.allow = None if allow is None else set(allow)
+        self.disallow = None if disallow is None else set(disallow)
+        self.expandiupac = expandiupac is True
+        self.split = None
+        if split is not None:
+            self.split = [split] if isinstance(split, int) else list(split)
+        self.sort = sort
+        self.sortnp, self.sortmem, self.sortcols = sortnp, sortmem, sortcols
+        self.parallel = parallel
+        self.sequences = sequences
+        self.device = device
+
+    # ------------------------------------------------------------------ device path
+    def device_geometry(self):
+        """(L, D, R) when this option set is the accelerated krisp_fasta combination."""
+        if self.kmers is None or len(self.kmers) != 1:
+            return None
+        k = self.kmers[0]
+        if not (1 <= k <= 32) or not self.complements or self.canonicals:
+            return None
+        if self.allow is not None or self.expandiupac or self.disallow != {"N", "n"}:
+            return None
+        if self.omitsoft == self.mapsoft:
+            return None
+        if self.sort is not True or self.sortcols is None or list(self.sortcols) != [0, 2]:
+            return None
+        if self.split is None or len(self.split) != 2:
+            return None
+        a, b = self.split
+        if a < 0 or b > 0 or a - b > k:
+            return None
+        geo = (a, 0, k - a) if b == 0 else (a, k - a + b, -b)     # kstream.py:824-830
+        if geo[1] > 16:
+            return None
+        return geo
+
+    def _device_keys(self, sequences, geo):
+        from . import _native
+        L, D, R = geo
+        records = fasta.read_records(sequences)
+        rna = bool(fasta.detect_rna(records))
+        bases = fasta.to_bases(records, rna)
+        fasta.check_special(bases, L + D + R, self.omitsoft)
+        with _native.Engine(device=self.device) as eng:
+            eng.set_params(L, D, R, omit_soft=self.omitsoft, max_bases=len(bases))
+            eng.add(0, bases)
+            keys = eng.keys(0).copy()
+        return keys, rna
+
+    # ------------------------------------------------------------------ host chain
+    def _host_stream(self, sequences):
+        records = [r.decode("latin-1") for r in fasta.read_records(sequences)]
+        rna = None
+        for s in records:                                    # kstream.py:481-508
+            if "T" in s or "t" in s:
+                rna = False
+                break
+            if "U" in s or "u" in s:
+                rna = True
+                break
+        seqs = iter(records)
+        if rna:
+            seqs = (s.replace("U", "T").replace("u", "t") for s in seqs)
+        if self.kmers is not None:
+            ks = self.kmers
+            seqs = (s[i:i + k] for s in seqs for k in ks for i in range(len(s) - k + 1))
+        if self.omitsoft:
+            seqs = (s for s in seqs if s.isupper())
+        if self.mapsoft:
+            seqs = (s.upper() for s in seqs)
+        if self.complements:
+            seqs = (x for s in seqs for x in (s, _revcomp(s)))
+        if self.allow is not None:
+            allow = self.allow
+            seqs = (s for s in seqs if set(s) <= allow)
+        if self.disallow is not None:
+            bad = self.disallow
+            seqs = (s for s in seqs if bad.isdisjoint(s))
+        if self.expandiupac:
+            seqs = self._expand(seqs)
+        if self.canonicals:
+            seqs = (min(s, _revcomp(s)) for s in seqs)
+        if self.split is not None:
+            seqs = (self._split_one(s) for s in seqs)
+        return seqs, rna
+
+    @staticmethod
+    def _expand(seqs):
+        for s in seqs:
+            pos = [i for i, c in enumerate(s) if c in IUPAC_BASE]
+            if not pos:
+                yield s
+                continue
+            t = list(s)
+            for combo in itertools.product(*[IUPAC_BASE[s[i]] for i in pos]):
+                for i, c in zip(pos, combo):
+                    t[i] = c
+                yield "".join(t)
+
+    def _split_one(self, s):
+        head, tail = [], []
+        for z in self.split:
+            if z >= 0:
+                head.append(s[:z])
+                s = s[z:]
+            else:
+                tail.append(s[z:])
+                s = s[:z]
+        return ",".join(head + [s] + tail)
+
+    def _host_sorted(self, lines):
+        """LC_ALL=C sort [-t, -kN,N ...] semantics (kstream.py:83-119): keys in byte
+        order, then GNU sort's whole-line last-resort compare."""
+        cols = self.sortcols
+        if cols is None:
+            return sorted(lines)
+
+        def key(ln):
+            f = ln.split(",")
+            return tuple(f[c] if c < len(f) else "" for c in cols) + (ln,)
+        return sorted(lines, key=key)
+
+    # ------------------------------------------------------------------ public surface
+    def __call__(self, sequences):
+        geo = self.device_geometry()
+        if geo is not None:
+            keys, rna = self._device_keys(sequences, geo)
+            for s in range(0, len(keys), _WRITE_CHUNK):
+                blob = codec.keys_to_lines_bytes(keys[s:s + _WRITE_CHUNK], *geo, rna=rna)
+                yield from blob.decode("ascii").split("\n")[:-1]
+            return
+        seqs, rna = self._host_stream(sequences)
+        if self.sort:
+            seqs = self._host_sorted(list(seqs))
+        if rna:
+            seqs = (s.replace("T", "U").replace("t", "u") for s in seqs)
+        yield from seqs
+
+    def __iter__(self):
+        return iter(self.__call__(self.sequences))
+
+    def write(self, filename, sequences=None):
+        """kstream.py:250-325: write (sorted) k-mers, return their number."""
+        if sequences is None:
+            sequences = self.sequences
+        geo = self.device_geometry()
+        if geo is not None:
+            keys, rna = self._device_keys(sequences, geo)
+            with open(filename, "wb") as f:
+                for s in range(0, len(keys), _WRITE_CHUNK):
+                    f.write(codec.keys_to_lines_bytes(keys[s:s + _WRITE_CHUNK], *geo, rna=rna))
+            return int(len(keys))
+        seqs, rna = self._host_stream(sequences)
+        if rna:
+            seqs = (s.replace("T", "U").replace("t", "u") for s in seqs)
+        lines = list(seqs)
+        if self.sort:
+            lines = self._host_sorted(lines)
+        with open(filename, "w") as f:
+            for ln in lines:
+                f.write(ln + "\n")
+        return len(lines)
+
+
+def parseArgs(sys_args):
+    """kstream.py:835-922."""
+    p = argparse.ArgumentParser(
+        description="Read and parse kmers from fasta or kmer stream\nCompatible with gz, bz2, and stdin.",
+        prog="kstream", formatter_class=argparse.RawTextHelpFormatter)
+    p.add_argument("file", nargs="?", type=str, default="-",
+                   help="Fasta file to read. .gz, .bz2, default stdin")
+    p.add_argument("-k", "--kmers", type=int, nargs="+",
+                   help="Convert sequences into kmers of given length(s).")
+    g = p.add_mutually_exclusive_group()
+    g.add_argument("--canonicals", action="store_true",
+                   help="Print canonical sequences (alphabetically first)")
+    g.add_argument("--complements", action="store_true", help="Add reverse complement to stream")
+    p.add_argument("--disallow", type=str, help="Omit sequences containing dissallowed nucleotides")
+    p.add_argument("--allow", type=str, help="Only accept sequences containing allowed nucleotides")
+    p.add_argument("--expand-iupac", action="store_true",
+                   help="Expand IUPAC nucleotide codes (including N's)")
+    p.add_argument("--omit-softmask", action="store_true", help="Omit sequences containing soft masking")
+    p.add_argument("--map-softmask", action="store_true", help="Unmask sequences containing soft masking")
+    p.add_argument("--split", nargs="+", type=int, help="Split kmers into columns and delimit by ','")
+    p.add_argument("-p", "--parallel", type=int, default=1, help="Number of processors to use. Default 1")
+    p.add_argument("-s", "--sort", action="store_true", help="Sort resulting kmers")
+    p.add_argument("--sort-np", type=int, default=1, help="Number of processores to use for sorting")
+    p.add_argument("--sort-mem", type=str, help="Amount of memory to use, see linux sort mem usage")
+    p.add_argument("--sort-cols", nargs="+", type=int, help="Sort based on these columns, 0-based indexing")
+    p.add_argument("--output", help="Write output to file as opposed to terminal")
+    p.add_argument("--device", type=int, default=0, help="GPU to use for the accelerated combination")
+    p.add_argument("--version", action="version", version="%(prog)s 1.0")
+    return p.parse_args(sys_args)
+
+
+def main(argv=None):
+    args = parseArgs(sys.argv[1:] if argv is None else argv)
+    streamer = kstream(kmers=args.kmers, complements=args.complements, canonicals=args.canonicals,
+                       allow=args.allow, disallow=args.disallow, omitsoft=args.omit_softmask,
+                       mapsoft=args.map_softmask, expandiupac=args.expand_iupac, split=args.split,
+                       parallel=args.parallel, sort=args.sort, sortnp=args.sort_np,
+                       sortmem=args.sort_mem, sortcols=args.sort_cols, device=args.device)
+    source = args.file
+    if source == "-":
+        source = iter(sys.stdin.buffer.read().splitlines())
+    if args.output is not None:
+        with open(args.output, "w") as fout:
+            for seq in streamer(source):
+                print(seq, file=fout)
+    else:
+        for seq in streamer(source):
+            print(seq)
+
+
+if __name__ == "__main__":
+    main()
