@@ -34,18 +34,20 @@ struct Geom {
     int omit;       // soft-mask rule
 };
 
-#define NWG 256            // persistent workgroups of the histogram / pass-1 kernels (one per CU)
-#define BIG_T 1024         // threads of those workgroups
+#define NWG 1024           // persistent workgroups of the histogram / pass-1 kernels (4 per CU)
+#define P1_T 256           // threads of those workgroups
+#define BIG_T 1024         // threads of a pass-2 workgroup (one per top-byte bucket)
 #define LS_T 2048u         // local-sort chunk window (keys)
 #define LS_CAP 4096u       // local-sort capacity (keys in LDS)
-#define LS_THREADS 256
+#define LS_THREADS 512
 #define LS_PER (LS_CAP / LS_THREADS)
+#define LS_WPT (LS_NB / 2 / LS_THREADS)   // packed counter words per thread in the scan
 #define LS_NB 4096u        // sub-bins of the LDS bucket sort
 #define LS_BIN_LIMIT 48u   // a fuller sub-bin switches the chunk to the bitonic network
 #define OVF_MAX 4096       // oversized-bucket list capacity
 #define IS_SUB 2048u       // anchor sub-tile of the intersect kernel
 #define IS_THREADS 256
-#define HIST_BITS 15       // LDS histogram bits per sweep (128 KiB of u32 counters)
+#define IS_NB 4096u        // sub-bins over the sub-tile's prefix span
 
 __device__ __forceinline__ u64 layout_key(u64 w, const Geom& g) {
     return (w & g.mL) | ((w << g.sR) & g.mR) | ((w >> g.sD) & g.mD);
@@ -118,23 +120,18 @@ __global__ void k_pack(const uint8_t* __restrict__ bases, u64 n, u64* __restrict
 }
 
 // ----------------------------------------------------------------------------
-// K2  per-workgroup histogram of the top-b key bits, straight from the codes.
-// One sweep counts the keys whose top (b-15) bits equal `sweep` into a 2^15-bin
-// LDS histogram (plain u32 counters), then stores it to partial[wg][.].
+// K2  per-workgroup histogram of the top key byte, straight from the codes.
+// (The finer digit of pass 2 is counted by the pass-2 workgroup itself.)
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(BIG_T) void k_hist(const u64* __restrict__ codes,
-                                                const u32* __restrict__ bad, u64 nwords,
-                                                u32* __restrict__ partial, Geom g, int sweep) {
-    extern __shared__ __attribute__((aligned(16))) u32 lhist[];
-    const int hb = g.b < HIST_BITS ? g.b : HIST_BITS;
-    const u32 nbins = 1u << hb;
-    for (u32 i = threadIdx.x; i < nbins; i += BIG_T) lhist[i] = 0;
+__global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, const u32* __restrict__ bad,
+                                               u64 nwords, u32* __restrict__ partial8, Geom g) {
+    __shared__ u32 lhist[256];
+    lhist[threadIdx.x] = 0;
     __syncthreads();
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
-    const int hi_bits = g.b - hb;   // bits selected by the sweep
-    for (u64 w = w0 + threadIdx.x; w < w1; w += BIG_T) {
+    for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
         u64 c0 = codes[w], c1 = codes[w + 1];
@@ -142,14 +139,12 @@ __global__ __launch_bounds__(BIG_T) void k_hist(const u64* __restrict__ codes,
         for (int j = 0; j < 32; j++) {
             u64 kf, kr;
             if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
-            u32 df = (u32)(kf >> g.rb), dr = (u32)(kr >> g.rb);
-            if ((int)(df >> hb) == sweep || hi_bits == 0) atomicAdd(&lhist[df & (nbins - 1)], 1u);
-            if ((int)(dr >> hb) == sweep || hi_bits == 0) atomicAdd(&lhist[dr & (nbins - 1)], 1u);
+            atomicAdd(&lhist[(u32)(kf >> 56)], 1u);
+            atomicAdd(&lhist[(u32)(kr >> 56)], 1u);
         }
     }
     __syncthreads();
-    u32* row = partial + ((u64)blockIdx.x << g.b) + ((u64)sweep << hb);
-    for (u32 i = threadIdx.x; i < nbins; i += BIG_T) row[i] = lhist[i];
+    partial8[(u64)blockIdx.x * 256 + threadIdx.x] = lhist[threadIdx.x];
 }
 
 // ----------------------------------------------------------------------------
@@ -178,27 +173,28 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* lds_waves /* >= 17 u3
 }
 
 // ----------------------------------------------------------------------------
-// K2b  one workgroup per top digit d1: column sums -> global fine histogram,
-// row sums -> per-workgroup pass-1 cursor offsets (exclusive over workgroups).
+// K2b  (single workgroup, 256 threads) thread d walks column d of partial8[NWG][256]:
+// in place exclusive prefix over the workgroups (= that workgroup's private pass-1
+// cursor offset inside bucket d), then a scan over d gives the bucket bases.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(NWG) void k_reduce(const u32* __restrict__ partial, u32* __restrict__ hist,
-                                               u32* __restrict__ rowoff, u32* __restrict__ tot1, int b) {
+__global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32* __restrict__ base1) {
     __shared__ u32 waves[17];
-    const u32 nb2 = 1u << (b - 8);
-    const u32 d1 = blockIdx.x;
-    const u64 base = (u64)d1 * nb2;
-    for (u32 c = threadIdx.x; c < nb2; c += NWG) {
-        u32 s = 0;
-        for (u32 wg = 0; wg < NWG; wg++) s += partial[((u64)wg << b) + base + c];
-        hist[base + c] = s;
+    const u32 d = threadIdx.x;
+    u32 run = 0;
+    for (u32 wg = 0; wg < NWG; wg += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = partial8[(u64)(wg + q) * 256 + d];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            partial8[(u64)(wg + q) * 256 + d] = run;
+            run += v[q];
+        }
     }
-    const u32* row = partial + ((u64)threadIdx.x << b) + base;
-    u32 s = 0;
-    for (u32 c = 0; c < nb2; c++) s += row[c];
     u32 total;
-    u32 ex = block_excl_scan(s, waves, total);
-    rowoff[(u64)threadIdx.x * 256 + d1] = ex;
-    if (threadIdx.x == 0) tot1[d1] = total;
+    u32 ex = block_excl_scan(run, waves, total);
+    base1[d] = ex;
+    if (d == 0) base1[256] = total;
 }
 
 // ----------------------------------------------------------------------------
@@ -206,33 +202,51 @@ __global__ __launch_bounds__(NWG) void k_reduce(const u32* __restrict__ partial,
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
     __shared__ u32 waves[17];
-    const u32 per = (n + 1023) / 1024;
+    // thread-contiguous slices of a multiple of 4 elements (in / out are 16-byte aligned)
+    const u32 per = ((n + 1023) / 1024 + 3) & ~3u;
     const u32 s0 = threadIdx.x * per;
     const u32 s1 = s0 + per < n ? s0 + per : n;
     u32 s = 0;
-    for (u32 i = s0; i < s1; i++) s += in[i];
+    for (u32 i = s0; i < s1; i += 4) {
+        if (i + 4 <= n) {
+            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            s += v.x + v.y + v.z + v.w;
+        } else {
+            for (u32 q = i; q < s1; q++) s += in[q];
+        }
+    }
     u32 total;
     u32 ex = block_excl_scan(s, waves, total);
-    for (u32 i = s0; i < s1; i++) { u32 v = in[i]; out[i] = ex; ex += v; }
+    for (u32 i = s0; i < s1; i += 4) {
+        if (i + 4 <= n) {
+            uint4 v = *reinterpret_cast<const uint4*>(in + i);
+            uint4 o;
+            o.x = ex; ex += v.x;
+            o.y = ex; ex += v.y;
+            o.z = ex; ex += v.z;
+            o.w = ex; ex += v.w;
+            *reinterpret_cast<uint4*>(out + i) = o;
+        } else {
+            for (u32 q = i; q < s1; q++) { u32 v = in[q]; out[q] = ex; ex += v; }
+        }
+    }
     if (threadIdx.x == 0) out[n] = total;
 }
 
 // ----------------------------------------------------------------------------
-// K3  pass 1: partition by the top 8 bits.  Same word ranges as k_hist, so the
-// workgroup's private cursors (base1[d] + rowoff[wg][d]) are exact: no global atomics.
+// K3  pass 1: partition by the top 8 bits.  Same word ranges as k_hist8, so the
+// workgroup's private cursors (base1[d] + its column prefix) are exact: no global atomics.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(BIG_T) void k_scatter1(const u64* __restrict__ codes,
-                                                    const u32* __restrict__ bad, u64 nwords,
-                                                    const u32* __restrict__ base1,
-                                                    const u32* __restrict__ rowoff,
-                                                    u64* __restrict__ dst, Geom g) {
+__global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes, const u32* __restrict__ bad,
+                                                  u64 nwords, const u32* __restrict__ base1,
+                                                  const u32* __restrict__ rowoff, u64* __restrict__ dst, Geom g) {
     __shared__ u32 cur[256];
-    if (threadIdx.x < 256) cur[threadIdx.x] = base1[threadIdx.x] + rowoff[(u64)blockIdx.x * 256 + threadIdx.x];
+    cur[threadIdx.x] = base1[threadIdx.x] + rowoff[(u64)blockIdx.x * 256 + threadIdx.x];
     __syncthreads();
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
-    for (u64 w = w0 + threadIdx.x; w < w1; w += BIG_T) {
+    for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
         u64 c0 = codes[w], c1 = codes[w + 1];
@@ -249,22 +263,58 @@ __global__ __launch_bounds__(BIG_T) void k_scatter1(const u64* __restrict__ code
 }
 
 // ----------------------------------------------------------------------------
-// K4  pass 2: workgroup d1 owns pass-1 bucket d1 and splits it by the next b-8 bits
+// K4  pass 2: workgroup d1 owns pass-1 bucket d1.  Phase A counts the next b-8
+// bits in LDS, a block scan turns the counts into cursors and publishes the fine
+// bucket offsets off[]; phase B scatters.  8 independent loads per thread in flight.
 // ----------------------------------------------------------------------------
+#define P2_UNROLL 8
 __global__ __launch_bounds__(BIG_T) void k_scatter2(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                    const u32* __restrict__ off, int b) {
+                                                    const u32* __restrict__ base1, u32* __restrict__ off,
+                                                    int b) {
     __shared__ u32 cur[1024];
+    __shared__ u32 waves[17];
     const u32 nb2 = 1u << (b - 8);
-    const u32 f0 = blockIdx.x * nb2;
-    for (u32 i = threadIdx.x; i < nb2; i += BIG_T) cur[i] = off[f0 + i];
-    __syncthreads();
-    const u32 s = off[f0], e = off[f0 + nb2];
+    const u32 d1 = blockIdx.x;
+    const u32 s = base1[d1], e = base1[d1 + 1];
     const int rb = 64 - b;
-    for (u32 i = s + threadIdx.x; i < e; i += BIG_T) {
-        u64 key = src[i];
-        u32 d2 = (u32)(key >> rb) & (nb2 - 1);
-        u32 slot = atomicAdd(&cur[d2], 1u);
-        dst[slot] = key;
+    cur[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 i0 = s; i0 < e; i0 += BIG_T * P2_UNROLL) {
+        u64 key[P2_UNROLL];
+#pragma unroll
+        for (int q = 0; q < P2_UNROLL; q++) {
+            u32 i = i0 + q * BIG_T + threadIdx.x;
+            key[q] = i < e ? src[i] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < P2_UNROLL; q++) {
+            u32 i = i0 + q * BIG_T + threadIdx.x;
+            if (i < e) atomicAdd(&cur[(u32)(key[q] >> rb) & (nb2 - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    u32 mine = cur[threadIdx.x];
+    u32 total;
+    u32 ex = block_excl_scan(mine, waves, total);
+    cur[threadIdx.x] = s + ex;
+    if (threadIdx.x < nb2) off[d1 * nb2 + threadIdx.x] = s + ex;
+    if (d1 == 255 && threadIdx.x == 0) off[256u * nb2] = e;
+    __syncthreads();
+    for (u32 i0 = s; i0 < e; i0 += BIG_T * P2_UNROLL) {
+        u64 key[P2_UNROLL];
+#pragma unroll
+        for (int q = 0; q < P2_UNROLL; q++) {
+            u32 i = i0 + q * BIG_T + threadIdx.x;
+            key[q] = i < e ? src[i] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < P2_UNROLL; q++) {
+            u32 i = i0 + q * BIG_T + threadIdx.x;
+            if (i < e) {
+                u32 slot = atomicAdd(&cur[(u32)(key[q] >> rb) & (nb2 - 1)], 1u);
+                dst[slot] = key[q];
+            }
+        }
     }
 }
 
@@ -341,13 +391,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
         }
     }
     __syncthreads();
-    // exclusive scan of the 4096 counters: thread t owns bins [16t, 16t+16) = 8 words
+    // exclusive scan of the 4096 16-bit counters: thread t owns LS_WPT consecutive words
     {
-        u32 w[8];
+        u32 w[LS_WPT];
         u32 sum = 0, mx = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            w[q] = cnt[tid * 8 + q];
+        for (int q = 0; q < LS_WPT; q++) {
+            w[q] = cnt[tid * LS_WPT + q];
             u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
             sum += a + c2;
             mx = max(mx, max(a, c2));
@@ -356,13 +406,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
         u32 total;
         u32 ex = block_excl_scan(sum, waves, total);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < LS_WPT; q++) {
             u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
             u32 lo16 = ex;
             ex += a;
             u32 hi16 = ex;
             ex += c2;
-            cnt[tid * 8 + q] = lo16 | (hi16 << 16);
+            cnt[tid * LS_WPT + q] = lo16 | (hi16 << 16);
         }
     }
     __syncthreads();
@@ -469,7 +519,7 @@ __device__ __forceinline__ bool passes_filter(u64 im, u64 om, int D) {
 // K6  n-way intersection.  One workgroup per chunk of the anchor genome: the
 // distinct (left,right) prefixes of the chunk go to LDS; every genome (the
 // anchor included) streams its keys of the same bucket range past them
-// (binary search in LDS), OR-ing a presence bit and the diagnostic-column masks.
+// (order-preserving sub-bins in LDS: ~2 probes per key), OR-ing a presence bit and the diagnostic-column masks.
 // Survivors are written in order to tmp[anchor offset ...]; chunkcnt[j] = count.
 // ----------------------------------------------------------------------------
 #define MAXG 32
@@ -485,11 +535,36 @@ struct IsectArgs {
     int apply_filter;
 };
 
+template <bool WIDE>
+__device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first, u64 last, int sh,
+                                            const u64* heads, const unsigned short* binstart, u32* present,
+                                            u64* inm, u64* outm, const Geom& g, int LR) {
+    u64 pre = key & g.pmask;
+    if (pre < first || pre > last) return;
+    u32 sb = (u32)((pre - first) >> sh);
+    u32 h = binstart[sb];
+    const u32 hend = binstart[sb + 1];
+    for (; h < hend; h++) {
+        if (heads[h] == pre) {
+            atomicOr(&present[h], 1u << gi);
+            if (g.D > 0) {
+                u64 dm = diag_mask(key, LR, g.D);
+                if (WIDE) atomicOr((u64*)(ing ? &inm[h] : &outm[h]), dm);
+                else atomicOr((u64*)&inm[h], ing ? dm : (dm << 32));   // D <= 8: in | out<<32
+            }
+            return;
+        }
+    }
+}
+
+#define IS_UNROLL 4
+template <bool WIDE>
 __global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
     __shared__ __attribute__((aligned(16))) u64 heads[IS_SUB];
     __shared__ __attribute__((aligned(16))) u64 inm[IS_SUB];
-    __shared__ __attribute__((aligned(16))) u64 outm[IS_SUB];
+    __shared__ __attribute__((aligned(16))) u64 outm[WIDE ? IS_SUB : 1];
     __shared__ u32 present[IS_SUB];
+    __shared__ unsigned short binstart[IS_NB + 2];
     __shared__ u32 waves[17];
     const u32 tid = threadIdx.x;
     const u32 lo = a.chunkstart[blockIdx.x], hi = a.chunkstart[blockIdx.x + 1];
@@ -522,30 +597,40 @@ __global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
         }
         __syncthreads();
         if (nheads == 0) continue;
-        for (u32 h = tid; h < nheads; h += IS_THREADS) { present[h] = 0; inm[h] = 0; outm[h] = 0; }
-        __syncthreads();
         const u64 first = heads[0], last = heads[nheads - 1];
+        const u64 span = last - first;
+        const int sh = span < IS_NB ? 0 : (64 - __clzll((long long)span) - 12);
+        // order-preserving sub-bins over [first, last]: binstart[sb] = #heads with bin < sb
+        for (u32 h = tid; h < nheads; h += IS_THREADS) {
+            present[h] = 0;
+            inm[h] = 0;
+            if (WIDE) outm[h] = 0;
+            u32 sb = (u32)((heads[h] - first) >> sh);
+            u32 prev = h ? (u32)((heads[h - 1] - first) >> sh) + 1 : 0;
+            for (u32 q = prev; q <= sb; q++) binstart[q] = (unsigned short)h;
+        }
+        {
+            u32 lastbin = (u32)(span >> sh);
+            for (u32 q = lastbin + 1 + tid; q <= IS_NB; q += IS_THREADS) binstart[q] = (unsigned short)nheads;
+        }
+        __syncthreads();
         const u32 fl = (u32)(first >> g.rb);
         const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
         for (int gi = 0; gi < a.n; gi++) {
             const u64* K = a.keys[gi];
             const u32 s = a.off[gi][fl], e = a.off[gi][fh];
             const bool ing = (a.ingroup_bits >> gi) & 1;
-            for (u32 i = s + tid; i < e; i += IS_THREADS) {
-                u64 key = K[i];
-                u64 pre = key & g.pmask;
-                if (pre < first || pre > last) continue;
-                u32 l = 0, r = nheads;
-                while (l < r) {
-                    u32 mid = (l + r) >> 1;
-                    if (heads[mid] < pre) l = mid + 1; else r = mid;
+            for (u32 i0 = s; i0 < e; i0 += IS_THREADS * IS_UNROLL) {
+                u64 key[IS_UNROLL];
+#pragma unroll
+                for (int q = 0; q < IS_UNROLL; q++) {
+                    u32 i = i0 + q * IS_THREADS + tid;
+                    key[q] = i < e ? K[i] : 0;
                 }
-                if (l < nheads && heads[l] == pre) {
-                    atomicOr(&present[l], 1u << gi);
-                    if (g.D > 0) {
-                        u64 dm = diag_mask(key, LR, g.D);
-                        atomicOr((u64*)(ing ? &inm[l] : &outm[l]), dm);
-                    }
+#pragma unroll
+                for (int q = 0; q < IS_UNROLL; q++) {
+                    u32 i = i0 + q * IS_THREADS + tid;
+                    if (i < e) isect_probe<WIDE>(key[q], gi, ing, first, last, sh, heads, binstart, present, inm, outm, g, LR);
                 }
             }
         }
@@ -553,17 +638,20 @@ __global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
         for (u32 i0 = 0; i0 < nheads; i0 += IS_THREADS) {
             u32 h = i0 + tid;
             bool ok = false;
+            u64 im = 0, om = 0;
             if (h < nheads) {
                 ok = present[h] == full;
-                if (ok && a.apply_filter && g.D > 0) ok = passes_filter(inm[h], outm[h], g.D);
+                im = WIDE ? inm[h] : (inm[h] & 0xFFFFFFFFull);
+                om = WIDE ? outm[h] : (inm[h] >> 32);
+                if (ok && a.apply_filter && g.D > 0) ok = passes_filter(im, om, g.D);
             }
             u32 tot;
             u32 pos = block_compact(ok, waves, tot);
             if (ok) {
                 kr_cand c;
                 c.prefix = heads[h];
-                c.in_mask = inm[h];
-                c.out_mask = outm[h];
+                c.in_mask = im;
+                c.out_mask = om;
                 a.tmp[(u64)sa + nout + pos] = c;
             }
             nout += tot;
@@ -573,6 +661,7 @@ __global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
     if (tid == 0) a.chunkcnt[blockIdx.x] = nout;
 }
 
+// ----------------------------------------------------------------------------
 // K6b  dense, ordered candidate list from the per-chunk runs
 __global__ void k_gather_cands(const kr_cand* __restrict__ tmp, const u32* __restrict__ chunkstart,
                                const u32* __restrict__ offA, const u32* __restrict__ chunkcnt,
@@ -677,11 +766,10 @@ struct Genome {
     size_t n_bases = 0;
     u64 nwords = 0;       // ceil(n/32)
     u64 nmax = 0;         // upper bound of the key count
-    DevBuf bases, keys, off, chunkstart;
+    DevBuf bases, keys, off, chunkstart, ovf;   // ovf: u32 count @0, uint2 segments @16
     u32 nchunks = 0;
     bool uploaded = false, sorted = false, finalized = false;
     int64_t count = -1;
-    u32 ovf = 0;
 };
 
 struct kr_ctx {
@@ -693,7 +781,7 @@ struct kr_ctx {
     size_t max_bases = 0;
     std::map<int, Genome> genomes;
     // scratch shared by all genome sorts
-    DevBuf codes, bad, partial, hist, rowoff, tot1, base1, tmpkeys, ovf_count, ovf_list;
+    DevBuf codes, bad, partial8, base1, tmpkeys;
     // candidates / records
     DevBuf candA, candB, chunkcnt, chunkpos, flags, blockcnt, blockpos, other, records, nrec;
     int64_t ncand = -1;
@@ -819,7 +907,6 @@ kr_ctx* kr_create(int device, size_t hbm_budget_bytes) {
         delete c;
         return nullptr;
     }
-    (void)hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 4u << HIST_BITS);
     return c;
 }
 
@@ -833,9 +920,10 @@ void kr_destroy(kr_ctx* c) {
         release(c, kv.second.keys);
         release(c, kv.second.off);
         release(c, kv.second.chunkstart);
+        release(c, kv.second.ovf);
     }
-    DevBuf* all[] = {&c->codes, &c->bad, &c->partial, &c->hist, &c->rowoff, &c->tot1, &c->base1,
-                     &c->tmpkeys, &c->ovf_count, &c->ovf_list, &c->candA, &c->candB, &c->chunkcnt,
+    DevBuf* all[] = {&c->codes, &c->bad, &c->partial8, &c->base1,
+                     &c->tmpkeys, &c->candA, &c->candB, &c->chunkcnt,
                      &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec};
     for (DevBuf* b : all) release(c, *b);
     for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -867,10 +955,10 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     g.mD = topbits(2 * k) & ~topbits(2 * (L + R));
     g.pmask = topbits(2 * (L + R));
     g.omit = softmask_mode == KR_SOFT_OMIT;
-    // fan-out: average fine bucket of ~1400 keys or fewer, 8 <= b <= 18
+    // fan-out: average fine bucket of ~1600 keys or fewer (limit LS_CAP - LS_T = 2048), 8 <= b <= 18
     u64 nmax = 2 * (u64)max_bases;
     int b = 8;
-    while (b < 18 && (nmax >> b) > 1400) b++;
+    while (b < 18 && (nmax >> b) > 1600) b++;
     g.b = b;
     g.rb = 64 - b;
     c->g = g;
@@ -897,18 +985,14 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
     if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
     if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
     if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
+    if ((rc = ensure(c, G.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
     // shared scratch sized for the largest genome
     const u64 mw = (c->max_bases + 31) / 32 + 4;
     if ((rc = ensure(c, c->codes, mw * 8))) return rc;
     if ((rc = ensure(c, c->bad, mw * 4))) return rc;
-    if ((rc = ensure(c, c->partial, (size_t)NWG * nb * 4))) return rc;
-    if ((rc = ensure(c, c->hist, (size_t)nb * 4))) return rc;
-    if ((rc = ensure(c, c->rowoff, (size_t)NWG * 256 * 4))) return rc;
-    if ((rc = ensure(c, c->tot1, 256 * 4))) return rc;
-    if ((rc = ensure(c, c->base1, 257 * 4))) return rc;
+    if ((rc = ensure(c, c->partial8, (size_t)NWG * 256 * 4))) return rc;
+    if ((rc = ensure(c, c->base1, 260 * 4))) return rc;
     if ((rc = ensure(c, c->tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
-    if ((rc = ensure(c, c->ovf_count, 16))) return rc;
-    if ((rc = ensure(c, c->ovf_list, (size_t)OVF_MAX * 8))) return rc;
     if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     G.uploaded = true;
@@ -927,6 +1011,8 @@ int kr_genome_sort(kr_ctx* c, int id) {
     u64* codes = (u64*)c->codes.p;
     u32* bad = (u32*)c->bad.p;
     const u64 nwp = G.nwords + 2;   // two pad words (all bad) so window j may read word w+1
+    G.sorted = G.finalized = false;
+    G.count = -1;
     {
         StageScope sc(c, KR_ST_PACK);
         u32 grid = (u32)std::min<u64>((nwp + 255) / 256, 4096);
@@ -935,74 +1021,87 @@ int kr_genome_sort(kr_ctx* c, int id) {
     }
     {
         StageScope sc(c, KR_ST_HIST);
-        const int hb = g.b < HIST_BITS ? g.b : HIST_BITS;
-        const int sweeps = 1 << (g.b - hb);
-        for (int s = 0; s < sweeps; s++)
-            hipLaunchKernelGGL(k_hist, dim3(NWG), dim3(BIG_T), 4u << hb, st, (const u64*)codes, (const u32*)bad,
-                               G.nwords, (u32*)c->partial.p, g, s);
+        hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                           (u32*)c->partial8.p, g);
     }
     {
         StageScope sc(c, KR_ST_SCAN);
-        hipLaunchKernelGGL(k_reduce, dim3(256), dim3(NWG), 0, st, (const u32*)c->partial.p, (u32*)c->hist.p,
-                           (u32*)c->rowoff.p, (u32*)c->tot1.p, g.b);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->tot1.p, (u32*)c->base1.p, 256u);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->hist.p, (u32*)G.off.p, nb);
-        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
-        hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
-                           (u32*)G.chunkstart.p);
+        hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)c->partial8.p, (u32*)c->base1.p);
     }
     u64* pass1_dst = g.b > 8 ? (u64*)c->tmpkeys.p : (u64*)G.keys.p;
     {
         StageScope sc(c, KR_ST_SCATTER1);
-        hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(BIG_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                           (const u32*)c->base1.p, (const u32*)c->rowoff.p, pass1_dst, g);
+        hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                           (const u32*)c->base1.p, (const u32*)c->partial8.p, pass1_dst, g);
     }
-    if (g.b > 8) {
+    {
         StageScope sc(c, KR_ST_SCATTER2);
-        hipLaunchKernelGGL(k_scatter2, dim3(256), dim3(BIG_T), 0, st, (const u64*)c->tmpkeys.p, (u64*)G.keys.p,
-                           (const u32*)G.off.p, g.b);
+        if (g.b > 8) {
+            hipLaunchKernelGGL(k_scatter2, dim3(256), dim3(BIG_T), 0, st, (const u64*)c->tmpkeys.p, (u64*)G.keys.p,
+                               (const u32*)c->base1.p, (u32*)G.off.p, g.b);
+        } else {
+            HIPCHK(c, hipMemcpyAsync(G.off.p, c->base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
+        hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
+                           (u32*)G.chunkstart.p);
     }
     {
         StageScope sc(c, KR_ST_LOCALSORT);
-        HIPCHK(c, hipMemsetAsync(c->ovf_count.p, 0, 16, st));
+        HIPCHK(c, hipMemsetAsync(G.ovf.p, 0, 16, st));
         hipLaunchKernelGGL(k_localsort, dim3(G.nchunks), dim3(LS_THREADS), 0, st, (u64*)G.keys.p,
-                           (const u32*)G.off.p, (const u32*)G.chunkstart.p, g.b, (u32*)c->ovf_count.p,
-                           (uint2*)c->ovf_list.p);
+                           (const u32*)G.off.p, (const u32*)G.chunkstart.p, g.b, (u32*)G.ovf.p,
+                           (uint2*)((char*)G.ovf.p + 16));
     }
-    // The oversized-bucket list is shared scratch: resolve it before the next genome reuses it.
-    // The check costs one 4-byte D2H + sync per genome; the bitonic fallback only runs when needed.
-    u32 novf = 0;
-    HIPCHK(c, hipMemcpyAsync(&novf, c->ovf_count.p, 4, hipMemcpyDeviceToHost, st));
+    G.sorted = true;      // enqueued; oversized buckets (if any) are resolved by finalize()
+    return KR_OK;
+}
+
+// Resolve what the asynchronous sort left open: the key count and -- rarely -- the
+// oversized buckets the LDS sort could not take (bitonic fallback in global memory).
+// One small D2H + sync for ALL listed genomes.
+static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
+    std::vector<Genome*> todo;
+    for (Genome* G : gs)
+        if (G->sorted && !G->finalized) todo.push_back(G);
+    if (todo.empty()) return KR_OK;
+    hipStream_t st = c->stream;
+    const u32 nb = 1u << c->g.b;
+    std::vector<u32> novf(todo.size()), total(todo.size());
+    for (size_t i = 0; i < todo.size(); i++) {
+        HIPCHK(c, hipMemcpyAsync(&novf[i], todo[i]->ovf.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(&total[i], (u32*)todo[i]->off.p + nb, 4, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
-    G.ovf = novf;
-    if (novf) {
-        StageScope sc(c, KR_ST_FALLBACK);
-        std::vector<uint2> segs;
-        if (novf > OVF_MAX) {
-            u32 total = 0;
-            HIPCHK(c, hipMemcpy(&total, (u32*)G.off.p + nb, 4, hipMemcpyDeviceToHost));
-            segs.push_back(make_uint2(0, total));
-            HIPCHK(c, hipMemcpy(c->ovf_list.p, segs.data(), 8, hipMemcpyHostToDevice));
-        } else {
-            segs.resize(novf);
-            HIPCHK(c, hipMemcpy(segs.data(), c->ovf_list.p, (size_t)novf * 8, hipMemcpyDeviceToHost));
-        }
-        u32 maxlen = 0;
-        for (auto& s : segs) maxlen = std::max(maxlen, s.y - s.x);
-        c->overflow_segments += (int64_t)segs.size();
-        dim3 grid(std::min<u32>((maxlen + 255) / 256, 65535), (u32)segs.size());
-        for (u64 kk = 2; kk < 2ull * maxlen; kk <<= 1) {
-            for (u64 j = kk >> 1; j > 0; j >>= 1) {
-                hipLaunchKernelGGL(k_bitonic_stage, grid, dim3(256), 0, st, (u64*)G.keys.p,
-                                   (const uint2*)c->ovf_list.p, (u32)kk, (u32)j, j == (kk >> 1) ? 1 : 0);
-                c->fallback_launches++;
+    for (size_t i = 0; i < todo.size(); i++) {
+        Genome& G = *todo[i];
+        G.count = total[i];
+        if (novf[i]) {
+            StageScope sc(c, KR_ST_FALLBACK);
+            std::vector<uint2> segs;
+            uint2* dsegs = (uint2*)((char*)G.ovf.p + 16);
+            if (novf[i] > OVF_MAX) {
+                segs.push_back(make_uint2(0, total[i]));
+                HIPCHK(c, hipMemcpy(dsegs, segs.data(), 8, hipMemcpyHostToDevice));
+            } else {
+                segs.resize(novf[i]);
+                HIPCHK(c, hipMemcpy(segs.data(), dsegs, (size_t)novf[i] * 8, hipMemcpyDeviceToHost));
+            }
+            u32 maxlen = 0;
+            for (auto& sg : segs) maxlen = std::max(maxlen, sg.y - sg.x);
+            c->overflow_segments += (int64_t)segs.size();
+            dim3 grid(std::min<u32>((maxlen + 255) / 256, 65535), (u32)segs.size());
+            for (u64 kk = 2; kk < 2ull * maxlen; kk <<= 1) {
+                for (u64 j = kk >> 1; j > 0; j >>= 1) {
+                    hipLaunchKernelGGL(k_bitonic_stage, grid, dim3(256), 0, st, (u64*)G.keys.p,
+                                       (const uint2*)dsegs, (u32)kk, (u32)j, j == (kk >> 1) ? 1 : 0);
+                    c->fallback_launches++;
+                }
             }
         }
-        HIPCHK(c, hipStreamSynchronize(st));
+        G.finalized = true;
     }
-    G.sorted = true;
-    G.finalized = true;
     return KR_OK;
 }
 
@@ -1010,15 +1109,10 @@ int64_t kr_genome_count(kr_ctx* c, int id) {
     if (!c) return KR_ERR_PARAM;
     auto it = c->genomes.find(id);
     if (it == c->genomes.end() || !it->second.sorted) return fail(c, KR_ERR_STATE, "genome %d not sorted", id);
-    Genome& G = it->second;
-    if (G.count < 0) {
-        u32 total = 0;
-        HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipMemcpyAsync(&total, (u32*)G.off.p + (1u << c->g.b), 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        G.count = total;
-    }
-    return G.count;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finalize(c, {&it->second});
+    if (rc) return rc;
+    return it->second.count;
 }
 
 int64_t kr_genome_add(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
@@ -1047,6 +1141,7 @@ int kr_genome_free(kr_ctx* c, int id) {
     release(c, it->second.keys);
     release(c, it->second.off);
     release(c, it->second.chunkstart);
+    release(c, it->second.ovf);
     c->genomes.erase(it);
     return KR_OK;
 }
@@ -1056,6 +1151,7 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     if (n > MAXG) return fail(c, KR_ERR_PARAM, "kr_intersect: at most %d genomes per call (cascade with kr_cands_merge)", MAXG);
     HIPCHK(c, hipSetDevice(c->device));
     IsectArgs a{};
+    int rc0;
     a.n = n;
     a.ingroup_bits = 0;
     a.apply_filter = apply_filter ? 1 : 0;
@@ -1072,6 +1168,7 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
         if (G.nmax < best) { best = G.nmax; anchor = i; }
         gs.push_back(&G);
     }
+    if ((rc0 = finalize(c, gs))) return rc0;
     Genome& A = *gs[anchor];
     a.anchor = anchor;
     a.chunkstart = (const u32*)A.chunkstart.p;
@@ -1085,7 +1182,10 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     hipStream_t st = c->stream;
     {
         StageScope sc(c, KR_ST_INTERSECT);
-        hipLaunchKernelGGL(k_intersect, dim3(A.nchunks), dim3(IS_THREADS), 0, st, a, c->g);
+        if (c->g.D > 8)
+            hipLaunchKernelGGL(k_intersect<true>, dim3(A.nchunks), dim3(IS_THREADS), 0, st, a, c->g);
+        else
+            hipLaunchKernelGGL(k_intersect<false>, dim3(A.nchunks), dim3(IS_THREADS), 0, st, a, c->g);
     }
     {
         StageScope sc(c, KR_ST_COMPACT);
@@ -1167,6 +1267,16 @@ int64_t kr_collect(kr_ctx* c, const int* ids, int n) {
     const u32 nc = (u32)c->ncand;
     c->nrecords = 0;
     if (nc == 0 || n == 0) return 0;
+    {
+        std::vector<Genome*> gs;
+        for (int i = 0; i < n; i++) {
+            auto it = c->genomes.find(ids[i]);
+            if (it == c->genomes.end() || !it->second.sorted)
+                return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
+            gs.push_back(&it->second);
+        }
+        if ((rc = finalize(c, gs))) return rc;
+    }
     for (int pass = 0; pass < 2; pass++) {
         HIPCHK(c, hipMemsetAsync(c->nrec.p, 0, 16, st));
         StageScope sc(c, KR_ST_COLLECT);
@@ -1267,7 +1377,7 @@ int64_t kr_debug_fetch(kr_ctx* c, int id, int what, void* out, size_t cap_bytes)
     switch (what) {
     case 0: src = c->codes.p; esz = 8; n = G.nwords + 2; break;
     case 1: src = c->bad.p; esz = 4; n = G.nwords + 2; break;
-    case 2: src = c->hist.p; esz = 4; n = nb; break;
+    case 2: src = c->base1.p; esz = 4; n = 257; break;
     case 3: src = G.off.p; esz = 4; n = nb + 1; break;
     case 4: src = c->g.b > 8 ? c->tmpkeys.p : G.keys.p; esz = 8; n = total; break;
     case 5: src = G.keys.p; esz = 8; n = total; break;

@@ -41,8 +41,9 @@ def _check_sorted(N, K, text, L, D, R, omit=False, stages=False):
             b = info["b"]
             top = (want >> np.uint64(64 - b)).astype(np.int64)
             hist = np.bincount(top, minlength=1 << b).astype(np.uint32)
-            got_hist = e.debug_fetch(0, 2, 1 << b)
-            assert np.array_equal(got_hist, hist), "fine histogram"
+            h8 = np.bincount((want >> np.uint64(56)).astype(np.int64), minlength=256)
+            base1 = np.concatenate([[0], np.cumsum(h8)]).astype(np.uint32)
+            assert np.array_equal(e.debug_fetch(0, 2, 257), base1), "top-byte bucket bases"
             off = np.concatenate([[0], np.cumsum(hist)]).astype(np.uint32)
             assert np.array_equal(e.debug_fetch(0, 3, (1 << b) + 1), off), "bucket offsets"
             p1 = e.debug_fetch(0, 4, len(want) + 4)
@@ -51,6 +52,7 @@ def _check_sorted(N, K, text, L, D, R, omit=False, stages=False):
             d1 = (p1 >> np.uint64(56)).astype(np.int64)
             assert np.all(np.diff(d1) >= 0), "pass-1 output partitioned by the top byte"
         got = e.keys(0)
+        info = e.debug_info()
         assert np.array_equal(got, want), info
         return info
 
