@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -36,7 +37,12 @@ struct Geom {
 
 #define NWG 1024           // persistent workgroups of the histogram / pass-1 kernels (4 per CU)
 #define P1_T 256           // threads of those workgroups
-#define BIG_T 1024         // threads of a pass-2 workgroup (one per top-byte bucket)
+#define P1_WORDS 64         // code words per pass-1 tile (2048 positions, <= 4096 keys)
+#define P1_KPT 16          // keys per thread per tile: 8 positions x 2 strands
+#define P1_STAGE (P1_WORDS * 64)
+#define P2_TILE 4096u      // keys per pass-2 tile
+#define P2_T 512           // threads of a pass-2 workgroup
+#define P2_KPT (P2_TILE / P2_T)
 #define LS_T 2048u         // local-sort chunk window (keys)
 #define LS_CAP 4096u       // local-sort capacity (keys in LDS)
 #define LS_THREADS 512
@@ -46,7 +52,7 @@ struct Geom {
 #define LS_BIN_LIMIT 48u   // a fuller sub-bin switches the chunk to the bitonic network
 #define OVF_MAX 4096       // oversized-bucket list capacity
 #define IS_SUB 2048u       // anchor sub-tile of the intersect kernel
-#define IS_THREADS 256
+#define IS_THREADS 512
 #define IS_NB 4096u        // sub-bins over the sub-tile's prefix span
 
 __device__ __forceinline__ u64 layout_key(u64 w, const Geom& g) {
@@ -177,7 +183,8 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* lds_waves /* >= 17 u3
 // in place exclusive prefix over the workgroups (= that workgroup's private pass-1
 // cursor offset inside bucket d), then a scan over d gives the bucket bases.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32* __restrict__ base1) {
+__global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32* __restrict__ base1,
+                                                 u32* __restrict__ tp, u32* __restrict__ tiled1) {
     __shared__ u32 waves[17];
     const u32 d = threadIdx.x;
     u32 run = 0;
@@ -195,6 +202,13 @@ __global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32
     u32 ex = block_excl_scan(run, waves, total);
     base1[d] = ex;
     if (d == 0) base1[256] = total;
+    // pass-2 tiles never straddle a bucket: tp[d] = first tile of bucket d, tiled1[tile] = its bucket
+    const u32 ntile = (run + P2_TILE - 1) / P2_TILE;
+    u32 ttotal;
+    u32 t0 = block_excl_scan(ntile, waves, ttotal);
+    tp[d] = t0;
+    if (d == 0) tp[256] = ttotal;
+    for (u32 t = 0; t < ntile; t++) tiled1[t0 + t] = d;
 }
 
 // ----------------------------------------------------------------------------
@@ -234,86 +248,185 @@ __global__ __launch_bounds__(1024) void k_scan(const u32* __restrict__ in, u32* 
 }
 
 // ----------------------------------------------------------------------------
-// K3  pass 1: partition by the top 8 bits.  Same word ranges as k_hist8, so the
-// workgroup's private cursors (base1[d] + its column prefix) are exact: no global atomics.
+// K3  pass 1: partition by the top 8 bits, LDS-staged so that global stores are
+// coalesced runs.  Same word ranges as k_hist8, so the workgroup's private cursors
+// (base1[d] + its column prefix) are exact: no global atomics.  Per tile of 64 code
+// words: generate <= 4096 keys, rank them per digit with LDS atomics, scan the 256
+// digit counts, stage the keys digit-sorted in LDS, copy the runs out.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                   u64 nwords, const u32* __restrict__ base1,
                                                   const u32* __restrict__ rowoff, u64* __restrict__ dst, Geom g) {
+    __shared__ __attribute__((aligned(16))) u64 stage[P1_STAGE];
     __shared__ u32 cur[256];
-    cur[threadIdx.x] = base1[threadIdx.x] + rowoff[(u64)blockIdx.x * 256 + threadIdx.x];
-    __syncthreads();
+    __shared__ u32 cnt[256];
+    __shared__ u32 delta[256];
+    __shared__ u32 waves[17];
+    const u32 tid = threadIdx.x;
+    cur[tid] = base1[tid] + rowoff[(u64)blockIdx.x * 256 + tid];
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
-    for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
-        u32 b0 = bad[w], b1 = bad[w + 1];
-        if (b0 == 0xFFFFFFFFu) continue;
-        u64 c0 = codes[w], c1 = codes[w + 1];
-#pragma unroll 4
-        for (int j = 0; j < 32; j++) {
-            u64 kf, kr;
-            if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
-            u32 sf = atomicAdd(&cur[(u32)(kf >> 56)], 1u);
-            dst[sf] = kf;
-            u32 sr = atomicAdd(&cur[(u32)(kr >> 56)], 1u);
-            dst[sr] = kr;
+    for (u64 wt = w0; wt < w1; wt += P1_WORDS) {
+        const u64 w = wt + (tid >> 2);
+        const int j0 = (tid & 3) * 8;
+        u64 key[P1_KPT];
+        u32 r[P1_KPT];
+        u32 vm = 0;
+        cnt[tid] = 0;
+        if (w < w1) {
+            u32 b0 = bad[w], b1 = bad[w + 1];
+            if (b0 != 0xFFFFFFFFu) {
+                u64 c0 = codes[w], c1 = codes[w + 1];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    u64 kf, kr;
+                    if (window_keys(c0, c1, b0, b1, j0 + jj, g, kf, kr)) {
+                        key[2 * jj] = kf;
+                        key[2 * jj + 1] = kr;
+                        vm |= 3u << (2 * jj);
+                    }
+                }
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P1_KPT; q++)
+            if ((vm >> q) & 1) r[q] = atomicAdd(&cnt[(u32)(key[q] >> 56)], 1u);
+        __syncthreads();
+        u32 c = cnt[tid], total;
+        u32 ex = block_excl_scan(c, waves, total);
+        cnt[tid] = ex;
+        delta[tid] = cur[tid] - ex;
+        cur[tid] += c;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P1_KPT; q++)
+            if ((vm >> q) & 1) stage[cnt[(u32)(key[q] >> 56)] + r[q]] = key[q];
+        __syncthreads();
+        for (u32 p = tid; p < total; p += P1_T) {
+            u64 k2 = stage[p];
+            dst[p + delta[(u32)(k2 >> 56)]] = k2;
+        }
+        __syncthreads();
     }
 }
 
 // ----------------------------------------------------------------------------
-// K4  pass 2: workgroup d1 owns pass-1 bucket d1.  Phase A counts the next b-8
-// bits in LDS, a block scan turns the counts into cursors and publishes the fine
-// bucket offsets off[]; phase B scatters.  8 independent loads per thread in flight.
+// K4  pass 2 = segmented partition of the pass-1 buckets by the next b-8 bits, in
+// tiles of 4096 keys that never straddle a bucket (tp / tiled1 from k_reduce8):
+//   k_hist2    per-tile digit counts (LDS histogram)           -> tilehist[tile][bin]
+//   k_scan2    per bucket: bin totals -> fine offsets off[], per-tile bin bases (in place)
+//   k_scatter2 per tile: rank, scan, stage digit-sorted in LDS, coalesced runs out
+// No global atomics, any number of workgroups per CU.
 // ----------------------------------------------------------------------------
-#define P2_UNROLL 8
-__global__ __launch_bounds__(BIG_T) void k_scatter2(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                    const u32* __restrict__ base1, u32* __restrict__ off,
-                                                    int b) {
-    __shared__ u32 cur[1024];
-    __shared__ u32 waves[17];
+__global__ __launch_bounds__(P2_T) void k_hist2(const u64* __restrict__ src, const u32* __restrict__ base1,
+                                               const u32* __restrict__ tp, const u32* __restrict__ tiled1,
+                                               u32* __restrict__ tilehist, int b) {
+    __shared__ u32 h[1024];
+    const u32 tile = blockIdx.x;
+    if (tile >= tp[256]) return;
     const u32 nb2 = 1u << (b - 8);
-    const u32 d1 = blockIdx.x;
-    const u32 s = base1[d1], e = base1[d1 + 1];
+    const u32 d1 = tiled1[tile];
+    const u32 s = base1[d1] + (tile - tp[d1]) * P2_TILE;
+    const u32 e = min(base1[d1 + 1], s + P2_TILE);
     const int rb = 64 - b;
-    cur[threadIdx.x] = 0;
+    for (u32 i = threadIdx.x; i < nb2; i += P2_T) h[i] = 0;
     __syncthreads();
-    for (u32 i0 = s; i0 < e; i0 += BIG_T * P2_UNROLL) {
-        u64 key[P2_UNROLL];
+    u64 key[P2_KPT];
 #pragma unroll
-        for (int q = 0; q < P2_UNROLL; q++) {
-            u32 i = i0 + q * BIG_T + threadIdx.x;
-            key[q] = i < e ? src[i] : 0;
-        }
+    for (int q = 0; q < (int)P2_KPT; q++) {
+        u32 i = s + q * P2_T + threadIdx.x;
+        key[q] = i < e ? src[i] : 0;
+    }
 #pragma unroll
-        for (int q = 0; q < P2_UNROLL; q++) {
-            u32 i = i0 + q * BIG_T + threadIdx.x;
-            if (i < e) atomicAdd(&cur[(u32)(key[q] >> rb) & (nb2 - 1)], 1u);
-        }
+    for (int q = 0; q < (int)P2_KPT; q++) {
+        u32 i = s + q * P2_T + threadIdx.x;
+        if (i < e) atomicAdd(&h[(u32)(key[q] >> rb) & (nb2 - 1)], 1u);
     }
     __syncthreads();
-    u32 mine = cur[threadIdx.x];
+    for (u32 i = threadIdx.x; i < nb2; i += P2_T) tilehist[(u64)tile * nb2 + i] = h[i];
+}
+
+__global__ __launch_bounds__(1024) void k_scan2(u32* __restrict__ tilehist, const u32* __restrict__ base1,
+                                                const u32* __restrict__ tp, u32* __restrict__ off, int b) {
+    __shared__ u32 waves[17];
+    const u32 nb2 = 1u << (b - 8);
+    const u32 d1 = blockIdx.x, bin = threadIdx.x;
+    const u32 t0 = tp[d1], t1 = tp[d1 + 1];
+    u32 tot = 0;
+    if (bin < nb2)
+        for (u32 t = t0; t < t1; t++) tot += tilehist[(u64)t * nb2 + bin];
     u32 total;
-    u32 ex = block_excl_scan(mine, waves, total);
-    cur[threadIdx.x] = s + ex;
-    if (threadIdx.x < nb2) off[d1 * nb2 + threadIdx.x] = s + ex;
-    if (d1 == 255 && threadIdx.x == 0) off[256u * nb2] = e;
-    __syncthreads();
-    for (u32 i0 = s; i0 < e; i0 += BIG_T * P2_UNROLL) {
-        u64 key[P2_UNROLL];
-#pragma unroll
-        for (int q = 0; q < P2_UNROLL; q++) {
-            u32 i = i0 + q * BIG_T + threadIdx.x;
-            key[q] = i < e ? src[i] : 0;
+    u32 ex = block_excl_scan(tot, waves, total);
+    u32 run = base1[d1] + ex;
+    if (bin < nb2) {
+        off[d1 * nb2 + bin] = run;
+        for (u32 t = t0; t < t1; t++) {
+            u32 v = tilehist[(u64)t * nb2 + bin];
+            tilehist[(u64)t * nb2 + bin] = run;
+            run += v;
         }
+    }
+    if (d1 == 255 && bin == 0) off[256u * nb2] = base1[256];
+}
+
+__global__ __launch_bounds__(P2_T) void k_scatter2(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                   const u32* __restrict__ base1, const u32* __restrict__ tp,
+                                                   const u32* __restrict__ tiled1,
+                                                   const u32* __restrict__ tilehist, int b) {
+    __shared__ __attribute__((aligned(16))) u64 stage[P2_TILE];
+    __shared__ u32 cnt[1024];
+    __shared__ u32 delta[1024];
+    __shared__ u32 waves[17];
+    const u32 tile = blockIdx.x;
+    if (tile >= tp[256]) return;
+    const u32 tid = threadIdx.x;
+    const u32 nb2 = 1u << (b - 8);
+    const u32 d1 = tiled1[tile];
+    const u32 s = base1[d1] + (tile - tp[d1]) * P2_TILE;
+    const u32 e = min(base1[d1 + 1], s + P2_TILE);
+    const int rb = 64 - b;
+    u64 key[P2_KPT];
+    u32 r[P2_KPT];
 #pragma unroll
-        for (int q = 0; q < P2_UNROLL; q++) {
-            u32 i = i0 + q * BIG_T + threadIdx.x;
-            if (i < e) {
-                u32 slot = atomicAdd(&cur[(u32)(key[q] >> rb) & (nb2 - 1)], 1u);
-                dst[slot] = key[q];
-            }
+    for (int q = 0; q < (int)P2_KPT; q++) {
+        u32 i = s + q * P2_T + tid;
+        key[q] = i < e ? src[i] : 0;
+    }
+    // this thread scans bins [2 tid, 2 tid + 2) (nb2 <= 1024 = 2 * P2_T)
+    const u32 bin0 = 2 * tid, bin1 = 2 * tid + 1;
+    u32 tb0 = bin0 < nb2 ? tilehist[(u64)tile * nb2 + bin0] : 0;
+    u32 tb1 = bin1 < nb2 ? tilehist[(u64)tile * nb2 + bin1] : 0;
+    cnt[bin0] = 0;
+    cnt[bin1] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (int)P2_KPT; q++) {
+        u32 i = s + q * P2_T + tid;
+        if (i < e) r[q] = atomicAdd(&cnt[(u32)(key[q] >> rb) & (nb2 - 1)], 1u);
+    }
+    __syncthreads();
+    u32 c0 = cnt[bin0], c1 = cnt[bin1], total;
+    u32 ex = block_excl_scan(c0 + c1, waves, total);
+    cnt[bin0] = ex;
+    cnt[bin1] = ex + c0;
+    delta[bin0] = tb0 - ex;
+    delta[bin1] = tb1 - (ex + c0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (int)P2_KPT; q++) {
+        u32 i = s + q * P2_T + tid;
+        if (i < e) stage[cnt[(u32)(key[q] >> rb) & (nb2 - 1)] + r[q]] = key[q];
+    }
+    __syncthreads();
+    const u32 nt = e - s;
+#pragma unroll
+    for (int q = 0; q < (int)P2_KPT; q++) {
+        u32 p = q * P2_T + tid;
+        if (p < nt) {
+            u64 k2 = stage[p];
+            dst[p + delta[(u32)(k2 >> rb) & (nb2 - 1)]] = k2;
         }
     }
 }
@@ -533,12 +646,13 @@ struct IsectArgs {
     kr_cand* tmp;
     u32* chunkcnt;
     int apply_filter;
+    int dbg;   // ablation switches (KR_DBG env): 1 = no probes, 2 = no atomics, 4 = no streaming
 };
 
 template <bool WIDE>
 __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first, u64 last, int sh,
                                             const u64* heads, const unsigned short* binstart, u32* present,
-                                            u64* inm, u64* outm, const Geom& g, int LR) {
+                                            u64* inm, u64* outm, const Geom& g, int LR, int dbg = 0) {
     u64 pre = key & g.pmask;
     if (pre < first || pre > last) return;
     u32 sb = (u32)((pre - first) >> sh);
@@ -546,6 +660,7 @@ __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first
     const u32 hend = binstart[sb + 1];
     for (; h < hend; h++) {
         if (heads[h] == pre) {
+            if (dbg & 2) { asm volatile("" ::"v"(h)); return; }
             atomicOr(&present[h], 1u << gi);
             if (g.D > 0) {
                 u64 dm = diag_mask(key, LR, g.D);
@@ -557,15 +672,51 @@ __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first
     }
 }
 
-#define IS_UNROLL 4
+#define IS_APT (IS_SUB / IS_THREADS)    // anchor keys (and stream keys per batch) per thread
+#define IS_NW (IS_THREADS / 64)
+
+// ordered compaction of IS_APT flags per thread (element p = q * IS_THREADS + tid):
+// ballots go to LDS, one wave turns the IS_APT * IS_NW group counts into prefixes.
+// Returns the total; pos[q] = output slot of element q (valid where flag[q]).
+__device__ __forceinline__ u32 compact_flags(const bool (&flag)[IS_APT], u32 (&pos)[IS_APT], u64* masks,
+                                             u32* mpref) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 m[IS_APT];
+#pragma unroll
+    for (int q = 0; q < (int)IS_APT; q++) {
+        m[q] = __ballot(flag[q]);
+        if (lane == 0) masks[q * IS_NW + wave] = m[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int ng = IS_APT * IS_NW;     // <= 64 groups
+        u32 c = lane < ng ? (u32)__popcll(masks[lane]) : 0;
+        u32 x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane < ng) mpref[lane] = x - c;
+        if (lane == 63) mpref[64] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (int)IS_APT; q++)
+        pos[q] = mpref[q * IS_NW + wave] + (u32)__popcll(m[q] & ((1ull << lane) - 1));
+    return mpref[64];
+}
+
 template <bool WIDE>
-__global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
+__global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArgs a, Geom g) {
     __shared__ __attribute__((aligned(16))) u64 heads[IS_SUB];
     __shared__ __attribute__((aligned(16))) u64 inm[IS_SUB];
     __shared__ __attribute__((aligned(16))) u64 outm[WIDE ? IS_SUB : 1];
     __shared__ u32 present[IS_SUB];
     __shared__ unsigned short binstart[IS_NB + 2];
-    __shared__ u32 waves[17];
+    __shared__ u64 masks[64];
+    __shared__ u32 mpref[65];
+    __shared__ u32 sstart[MAXG], send[MAXG];
     const u32 tid = threadIdx.x;
     const u32 lo = a.chunkstart[blockIdx.x], hi = a.chunkstart[blockIdx.x + 1];
     if (lo >= hi) {
@@ -579,27 +730,38 @@ __global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
     u32 nout = 0;
     for (u32 sub = sa; sub < ea; sub += IS_SUB) {
         const u32 cnt = min(IS_SUB, ea - sub);
-        // distinct prefixes of the sub-tile, in order
-        u32 nheads = 0;
-        for (u32 i0 = 0; i0 < cnt; i0 += IS_THREADS) {
-            u32 p = i0 + tid;
-            bool ishead = false;
-            u64 pre = 0;
-            if (p < cnt) {
-                u32 gi = sub + p;
-                pre = KA[gi] & g.pmask;
-                ishead = (gi == 0) || ((KA[gi - 1] & g.pmask) != pre);
-            }
-            u32 tot;
-            u32 pos = block_compact(ishead, waves, tot);
-            if (ishead) heads[nheads + pos] = pre;
-            nheads += tot;
+        // all anchor loads of the sub-tile in flight at once
+        u64 ak[IS_APT], pk[IS_APT];
+#pragma unroll
+        for (int q = 0; q < (int)IS_APT; q++) {
+            u32 p = q * IS_THREADS + tid;
+            u32 gi = sub + p;
+            ak[q] = p < cnt ? KA[gi] : 0;
+            pk[q] = (p < cnt && gi > 0) ? KA[gi - 1] : 0;
         }
+        // distinct prefixes of the sub-tile, in order
+        bool flag[IS_APT];
+        u32 pos[IS_APT];
+#pragma unroll
+        for (int q = 0; q < (int)IS_APT; q++) {
+            u32 p = q * IS_THREADS + tid;
+            flag[q] = p < cnt && ((sub + p == 0) || ((pk[q] & g.pmask) != (ak[q] & g.pmask)));
+        }
+        const u32 nheads = compact_flags(flag, pos, masks, mpref);
+#pragma unroll
+        for (int q = 0; q < (int)IS_APT; q++)
+            if (flag[q]) heads[pos[q]] = ak[q] & g.pmask;
         __syncthreads();
         if (nheads == 0) continue;
         const u64 first = heads[0], last = heads[nheads - 1];
         const u64 span = last - first;
         const int sh = span < IS_NB ? 0 : (64 - __clzll((long long)span) - 12);
+        const u32 fl = (u32)(first >> g.rb);
+        const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
+        if (tid < (u32)a.n) {
+            sstart[tid] = a.off[tid][fl];
+            send[tid] = (a.dbg & 4) ? sstart[tid] : a.off[tid][fh];
+        }
         // order-preserving sub-bins over [first, last]: binstart[sb] = #heads with bin < sb
         for (u32 h = tid; h < nheads; h += IS_THREADS) {
             present[h] = 0;
@@ -614,48 +776,80 @@ __global__ __launch_bounds__(IS_THREADS) void k_intersect(IsectArgs a, Geom g) {
             for (u32 q = lastbin + 1 + tid; q <= IS_NB; q += IS_THREADS) binstart[q] = (unsigned short)nheads;
         }
         __syncthreads();
-        const u32 fl = (u32)(first >> g.rb);
-        const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
+        // every genome (anchor included) streams its keys of the bucket range past the heads;
+        // the first batch of genome g+1 is in flight while genome g is probed
+        u64 cur[IS_APT], nxt[IS_APT];
+        {
+            const u64* K = a.keys[0];
+            const u32 s0 = sstart[0], e0 = send[0];
+#pragma unroll
+            for (int q = 0; q < (int)IS_APT; q++) {
+                u32 i = s0 + q * IS_THREADS + tid;
+                cur[q] = i < e0 ? K[i] : 0;
+            }
+        }
         for (int gi = 0; gi < a.n; gi++) {
             const u64* K = a.keys[gi];
-            const u32 s = a.off[gi][fl], e = a.off[gi][fh];
+            const u32 s = sstart[gi], e = send[gi];
             const bool ing = (a.ingroup_bits >> gi) & 1;
-            for (u32 i0 = s; i0 < e; i0 += IS_THREADS * IS_UNROLL) {
-                u64 key[IS_UNROLL];
+            if (gi + 1 < a.n) {
+                const u64* K2 = a.keys[gi + 1];
+                const u32 s2 = sstart[gi + 1], e2 = send[gi + 1];
 #pragma unroll
-                for (int q = 0; q < IS_UNROLL; q++) {
-                    u32 i = i0 + q * IS_THREADS + tid;
-                    key[q] = i < e ? K[i] : 0;
-                }
-#pragma unroll
-                for (int q = 0; q < IS_UNROLL; q++) {
-                    u32 i = i0 + q * IS_THREADS + tid;
-                    if (i < e) isect_probe<WIDE>(key[q], gi, ing, first, last, sh, heads, binstart, present, inm, outm, g, LR);
+                for (int q = 0; q < (int)IS_APT; q++) {
+                    u32 i = s2 + q * IS_THREADS + tid;
+                    nxt[q] = i < e2 ? K2[i] : 0;
                 }
             }
+            for (u32 i0 = s; i0 < e; i0 += IS_SUB) {
+                if (i0 != s) {
+#pragma unroll
+                    for (int q = 0; q < (int)IS_APT; q++) {
+                        u32 i = i0 + q * IS_THREADS + tid;
+                        cur[q] = i < e ? K[i] : 0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < (int)IS_APT; q++) {
+                    u32 i = i0 + q * IS_THREADS + tid;
+                    if (i < e) {
+                        if (a.dbg & 1) asm volatile("" ::"v"(cur[q]));
+                        else
+                            isect_probe<WIDE>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm,
+                                              outm, g, LR, a.dbg);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < (int)IS_APT; q++) cur[q] = nxt[q];
         }
         __syncthreads();
-        for (u32 i0 = 0; i0 < nheads; i0 += IS_THREADS) {
-            u32 h = i0 + tid;
-            bool ok = false;
-            u64 im = 0, om = 0;
+        // survivors, in order
+        u64 im[IS_APT], om[IS_APT];
+#pragma unroll
+        for (int q = 0; q < (int)IS_APT; q++) {
+            u32 h = q * IS_THREADS + tid;
+            flag[q] = false;
+            im[q] = om[q] = 0;
             if (h < nheads) {
-                ok = present[h] == full;
-                im = WIDE ? inm[h] : (inm[h] & 0xFFFFFFFFull);
-                om = WIDE ? outm[h] : (inm[h] >> 32);
-                if (ok && a.apply_filter && g.D > 0) ok = passes_filter(im, om, g.D);
+                flag[q] = present[h] == full;
+                im[q] = WIDE ? inm[h] : (inm[h] & 0xFFFFFFFFull);
+                om[q] = WIDE ? outm[h] : (inm[h] >> 32);
+                if (flag[q] && a.apply_filter && g.D > 0) flag[q] = passes_filter(im[q], om[q], g.D);
             }
-            u32 tot;
-            u32 pos = block_compact(ok, waves, tot);
-            if (ok) {
-                kr_cand c;
-                c.prefix = heads[h];
-                c.in_mask = im;
-                c.out_mask = om;
-                a.tmp[(u64)sa + nout + pos] = c;
-            }
-            nout += tot;
         }
+        const u32 nsurv = compact_flags(flag, pos, masks, mpref);
+#pragma unroll
+        for (int q = 0; q < (int)IS_APT; q++) {
+            if (flag[q]) {
+                kr_cand c;
+                c.prefix = heads[q * IS_THREADS + tid];
+                c.in_mask = im[q];
+                c.out_mask = om[q];
+                a.tmp[(u64)sa + nout + pos[q]] = c;
+            }
+        }
+        nout += nsurv;
         __syncthreads();
     }
     if (tid == 0) a.chunkcnt[blockIdx.x] = nout;
@@ -781,7 +975,7 @@ struct kr_ctx {
     size_t max_bases = 0;
     std::map<int, Genome> genomes;
     // scratch shared by all genome sorts
-    DevBuf codes, bad, partial8, base1, tmpkeys;
+    DevBuf codes, bad, partial8, base1, tmpkeys, tp, tiled1, tilehist;
     // candidates / records
     DevBuf candA, candB, chunkcnt, chunkpos, flags, blockcnt, blockpos, other, records, nrec;
     int64_t ncand = -1;
@@ -922,7 +1116,7 @@ void kr_destroy(kr_ctx* c) {
         release(c, kv.second.chunkstart);
         release(c, kv.second.ovf);
     }
-    DevBuf* all[] = {&c->codes, &c->bad, &c->partial8, &c->base1,
+    DevBuf* all[] = {&c->codes, &c->bad, &c->partial8, &c->base1, &c->tp, &c->tiled1, &c->tilehist,
                      &c->tmpkeys, &c->candA, &c->candB, &c->chunkcnt,
                      &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec};
     for (DevBuf* b : all) release(c, *b);
@@ -993,6 +1187,12 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
     if ((rc = ensure(c, c->partial8, (size_t)NWG * 256 * 4))) return rc;
     if ((rc = ensure(c, c->base1, 260 * 4))) return rc;
     if ((rc = ensure(c, c->tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
+    {
+        const u64 ntmax = 2 * (u64)c->max_bases / P2_TILE + 260;
+        if ((rc = ensure(c, c->tp, 260 * 4))) return rc;
+        if ((rc = ensure(c, c->tiled1, ntmax * 4))) return rc;
+        if ((rc = ensure(c, c->tilehist, ntmax * (nb >> 8) * 4))) return rc;
+    }
     if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     G.uploaded = true;
@@ -1026,7 +1226,8 @@ int kr_genome_sort(kr_ctx* c, int id) {
     }
     {
         StageScope sc(c, KR_ST_SCAN);
-        hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)c->partial8.p, (u32*)c->base1.p);
+        hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)c->partial8.p, (u32*)c->base1.p,
+                           (u32*)c->tp.p, (u32*)c->tiled1.p);
     }
     u64* pass1_dst = g.b > 8 ? (u64*)c->tmpkeys.p : (u64*)G.keys.p;
     {
@@ -1037,8 +1238,15 @@ int kr_genome_sort(kr_ctx* c, int id) {
     {
         StageScope sc(c, KR_ST_SCATTER2);
         if (g.b > 8) {
-            hipLaunchKernelGGL(k_scatter2, dim3(256), dim3(BIG_T), 0, st, (const u64*)c->tmpkeys.p, (u64*)G.keys.p,
-                               (const u32*)c->base1.p, (u32*)G.off.p, g.b);
+            const u32 ntmax = (u32)(G.nmax / P2_TILE) + 257;
+            hipLaunchKernelGGL(k_hist2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)c->tmpkeys.p,
+                               (const u32*)c->base1.p, (const u32*)c->tp.p, (const u32*)c->tiled1.p,
+                               (u32*)c->tilehist.p, g.b);
+            hipLaunchKernelGGL(k_scan2, dim3(256), dim3(1024), 0, st, (u32*)c->tilehist.p, (const u32*)c->base1.p,
+                               (const u32*)c->tp.p, (u32*)G.off.p, g.b);
+            hipLaunchKernelGGL(k_scatter2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)c->tmpkeys.p,
+                               (u64*)G.keys.p, (const u32*)c->base1.p, (const u32*)c->tp.p,
+                               (const u32*)c->tiled1.p, (const u32*)c->tilehist.p, g.b);
         } else {
             HIPCHK(c, hipMemcpyAsync(G.off.p, c->base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
         }
@@ -1155,6 +1363,10 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     a.n = n;
     a.ingroup_bits = 0;
     a.apply_filter = apply_filter ? 1 : 0;
+    {
+        const char* e = getenv("KR_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
     int anchor = 0;
     u64 best = ~0ull;
     std::vector<Genome*> gs;
