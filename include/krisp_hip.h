@@ -91,6 +91,10 @@ int kr_genome_sort(kr_ctx*, int genome_id);
 /* upload + sort + sync; returns the number of k-mer records (>= 0). */
 int64_t kr_genome_add(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
 int64_t kr_genome_count(kr_ctx*, int genome_id);               /* syncs */
+/* Adopt an already sorted key array (the content of a sorted k-mer file the reference or
+ * extractSortedKmers wrote, kstream.py:832 lines packed by the host): builds the bucket grid
+ * only.  Lets mergeFiles (intersectAmplicons.py:232) run on files.  Returns n. */
+int64_t kr_genome_load_sorted(kr_ctx*, int genome_id, const uint64_t* keys, size_t n);
 int64_t kr_genome_fetch_keys(kr_ctx*, int genome_id, uint64_t* out, size_t cap);
 int     kr_genome_free(kr_ctx*, int genome_id);
 

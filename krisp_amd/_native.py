@@ -31,6 +31,7 @@ SYMBOLS = [
     ("kr_genome_sort", _c.c_int, [_P, _c.c_int]),
     ("kr_genome_add", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_genome_count", _c.c_int64, [_P, _c.c_int]),
+    ("kr_genome_load_sorted", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_genome_fetch_keys", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_genome_free", _c.c_int, [_P, _c.c_int]),
     ("kr_intersect", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
@@ -132,6 +133,11 @@ class Engine:
         self.upload(gid, bases)
         self.sort(gid)
         return self.count(gid)
+
+    def load_sorted(self, gid, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        return self._check(self.lib.kr_genome_load_sorted(self.ctx, gid, _ptr(keys) if len(keys) else None,
+                                                          len(keys)), "kr_genome_load_sorted")
 
     def count(self, gid):
         return self._check(self.lib.kr_genome_count(self.ctx, gid), "kr_genome_count")

@@ -444,6 +444,20 @@ __global__ void k_chunk_bounds(const u32* __restrict__ off, u32 nb, u32* __restr
     for (u32 j = jlo; j <= jhi; j++) chunkstart[j] = f;
 }
 
+// fine bucket offsets of an already sorted key array: off[f] = lower_bound(f << rb)
+__global__ void k_offsets_from_sorted(const u64* __restrict__ keys, u32 n, u32 nb, int rb, u32* __restrict__ off) {
+    u32 f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f > nb) return;
+    if (f == nb) { off[f] = n; return; }
+    const u64 target = (u64)f << rb;
+    u32 l = 0, r = n;
+    while (l < r) {
+        u32 mid = l + ((r - l) >> 1);
+        if (keys[mid] < target) l = mid + 1; else r = mid;
+    }
+    off[f] = l;
+}
+
 // ----------------------------------------------------------------------------
 // K5  local sort of one chunk (<= LS_CAP keys) in LDS, in place in global memory:
 // count into 4096 order-preserving sub-bins (16-bit LDS counters), scan, place,
@@ -1311,6 +1325,39 @@ static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
         G.finalized = true;
     }
     return KR_OK;
+}
+
+int64_t kr_genome_load_sorted(kr_ctx* c, int id, const uint64_t* keys, size_t n) {
+    if (!c || !c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
+    if (n > 2 * c->max_bases) return fail(c, KR_ERR_PARAM, "%zu keys exceed 2 * max_bases", n);
+    HIPCHK(c, hipSetDevice(c->device));
+    Genome& G = c->genomes[id];
+    G.id = id;
+    G.n_bases = 0;
+    G.nwords = 0;
+    G.nmax = std::max<u64>(n, 1);
+    const u32 nb = 1u << c->g.b;
+    G.nchunks = (u32)(G.nmax / LS_T) + 1;
+    int rc;
+    if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
+    if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
+    if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
+    if ((rc = ensure(c, G.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
+    hipStream_t st = c->stream;
+    if (n) HIPCHK(c, hipMemcpyAsync(G.keys.p, keys, n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_offsets_from_sorted, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u64*)G.keys.p,
+                       (u32)n, nb, c->g.rb, (u32*)G.off.p);
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
+    hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
+                       (u32*)G.chunkstart.p);
+    HIPCHK(c, hipMemsetAsync(G.ovf.p, 0, 16, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    G.uploaded = false;
+    G.sorted = true;
+    G.finalized = true;
+    G.count = (int64_t)n;
+    return (int64_t)n;
 }
 
 int64_t kr_genome_count(kr_ctx* c, int id) {

@@ -1,0 +1,410 @@
+"""`krisp_fasta` -- same command line and stage functions as the reference
+(krisp_fasta/krisp_fasta.py), with the k-mer generation / sort / multi-genome
+intersection / diagnostic filter running on the MI355X through libkrisp_hip.so.
+
+Seams kept:
+  extractSortedKmers(fasta, primer_left, primer_right, ampl_len, output, sortmem,
+                     parallel=1, verbose=True, omit=True)      krisp_fasta.py:16-66
+  mergeFiles(files, output, parallel=1, workdir=None, verbose=True)
+                                                               intersectAmplicons.py:232-310
+  filterAlignments(kmerfile, output, ingroup)                  filterAlignments.py:31-40
+  main()                                                       krisp_fasta.py:126-298
+main() does not round-trip through text files: genomes are sorted once on the
+device and intersected there (find_regions); the stage functions exist for
+interoperability with the reference's intermediate files and for stage-level
+parity tests.  There is no CPU implementation of the hot path behind any of them.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+from . import amplicon, codec, fasta
+from .kstream import kstream
+
+_FASTA_EXT = ("gz", "bz2", "fna", "fasta", "fa", "ffn", "frn")
+
+
+def basename(filename):
+    """shared.py:34-55: file name without fasta / compression endings."""
+    parts = Path(filename).name.split(".")
+    while parts[-1] in _FASTA_EXT:
+        parts.pop()
+    return ".".join(parts)
+
+
+def simplename(filename):
+    """shared.py:58-73: ... truncated at the first dot -- the genome's label."""
+    return basename(filename).split(".")[0]
+
+
+def prettyTime(t):
+    """shared.py:8-31."""
+    if t < 60:
+        return f"{t:.2f} seconds"
+    minutes = int(t / 60)
+    seconds = math.ceil(t - 60 * minutes)
+    return (f"{minutes} minute{'s' if minutes > 1 else ''} and "
+            f"{seconds} second{'s' if seconds > 1 else ''}")
+
+
+class UnsupportedGeometry(NotImplementedError):
+    pass
+
+
+def _check_geometry(L, D, R):
+    k = L + D + R
+    if k > 32:
+        raise UnsupportedGeometry(
+            f"amplicon length {k} > 32: the multi-word key path is not built yet "
+            "(a 64-bit key holds 32 bases)")
+    if D > 16:
+        raise UnsupportedGeometry(f"diagnostic length {D} > 16 exceeds the device mask format")
+
+
+# ----------------------------------------------------------------------------
+# the fused device flow used by main()
+# ----------------------------------------------------------------------------
+def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,
+                 device=0, verbose=False, keep_merged=False):
+    """FASTA files -> list of surviving groups (amplicon.Amplicon lists).
+
+    = extractSortedKmers per file + mergeFiles + filterAlignments of the reference
+    (krisp_fasta.py:237-272), on the GPU: one sort per genome, one n-way
+    intersection with the diagnostic filter fused in, one collect.
+    Returns (groups, stats)."""
+    from . import _native
+    k = amplicon_len
+    D_nominal = k - L - R
+    Le, De, Re = codec.effective_geometry(L, D_nominal, R)
+    _check_geometry(Le, De, Re)
+    files = list(ingroup_files) + list(outgroup_files)
+    # the reference filters whenever k > L + R (krisp_fasta.py:265); with R == 0 the
+    # diagnostic column is empty (kstream.py:824-830) and every group fails the filter
+    do_filter = k > L + R
+    quirk_all_fail = do_filter and De == 0
+    t0 = time.time()
+    texts, rna_any = [], False
+    for f in files:
+        records = fasta.read_records(f)
+        rna = bool(fasta.detect_rna(records))
+        rna_any = rna_any or rna
+        bases = fasta.to_bases(records, rna)
+        fasta.check_special(bases, k, omit_soft)
+        texts.append(bases)
+    if len(files) == 1:
+        # mergeFiles moves the lone k-mer file; its lines carry no label, so later stages
+        # label them with the file they read: simplename('merged_file.txt') (shared.py:373)
+        labels = ["merged_file"]
+    else:
+        labels = [simplename(f) for f in files]
+    ingroup_labels = frozenset(simplename(f) for f in ingroup_files)
+    flags = [lab in ingroup_labels for lab in labels]
+    stats = {"read_s": time.time() - t0}
+    t1 = time.time()
+    with _native.Engine(device=device) as eng:
+        eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(len(t) for t in texts))
+        counts = []
+        for i, t in enumerate(texts):
+            eng.upload(i, t)
+            eng.sort(i)
+        ids = list(range(len(files)))
+        ncand = eng.intersect(ids, flags, apply_filter=do_filter and not quirk_all_fail)
+        counts = [eng.count(i) for i in ids]
+        if verbose:
+            for f, c in zip(files, counts):
+                print(f"=> Extracted and sorted {c:,} {k}-kmers from {f}", file=sys.stderr)
+        records = eng.collect(ids) if (ncand and not quirk_all_fail) else np.empty(0, dtype=_native.RECORD)
+    stats.update(device_s=time.time() - t1, kmers=int(sum(counts)), candidates=int(ncand))
+    if quirk_all_fail:
+        return [], stats
+    groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
+    return groups, stats
+
+
+# ----------------------------------------------------------------------------
+# stage functions (reference signatures)
+# ----------------------------------------------------------------------------
+def extractSortedKmers(fasta_file, primer_left, primer_right, ampl_len, output,
+                       sortmem, parallel=1, verbose=True, omit=True, device=0):
+    """Fasta file -> sorted 'left,diag,right' k-mer file (krisp_fasta.py:16-66)."""
+    kw = dict(kmers=ampl_len, disallow="Nn", complements=True,
+              split=[primer_left, -primer_right], sort=True, sortmem=sortmem,
+              sortcols=[0, 2], sortnp=parallel, parallel=parallel, device=device)
+    kw["omitsoft" if omit else "mapsoft"] = True
+    ks = kstream(fasta_file, **kw)
+    if ks.device_geometry() is None:
+        raise UnsupportedGeometry(f"{primer_left}/{ampl_len - primer_left - primer_right}/"
+                                  f"{primer_right} is outside the device path")
+    t0 = time.time()
+    if verbose:
+        print(f"Extracting {ampl_len}-mers from {fasta_file} and saving to {output}", file=sys.stderr)
+    found = ks.write(output)
+    if verbose:
+        print(f"=> Extracted and sorted {found:,} {ampl_len}-kmers from {fasta_file} in "
+              f"{prettyTime(time.time() - t0)}", file=sys.stderr)
+
+
+def sortedKmersSerial(files, outputs, ampl_len, primer_left, primer_right, verbose=True,
+                      omit=True, device=0):
+    for f, o in zip(files, outputs):
+        extractSortedKmers(f, primer_left, primer_right, ampl_len, o, "80%", 1, verbose, omit, device)
+
+
+def sortedKmersParallel(files, outputs, ampl_len, primer_left, primer_right, parallel=1,
+                        verbose=True, omit=True, device=0):
+    """krisp_fasta.py:86-123.  One GPU sorts a genome in milliseconds; the reference's
+    process-per-genome fan-out has nothing left to hide, so this is the serial loop."""
+    sortedKmersSerial(files, outputs, ampl_len, primer_left, primer_right, verbose, omit, device)
+
+
+def _read_lines(path):
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    return lines
+
+
+def mergeFiles(files, output, parallel=1, workdir=None, verbose=True, device=0):
+    """Sorted 3-column k-mer files -> merged alignment file
+    (intersectAmplicons.py:232-310): every (left,right) pair present in ALL files,
+    one line 'left,diag,right,labels' per distinct sequence.  The keys of each file
+    are packed on the host and adopted by the device as a sorted genome
+    (kr_genome_load_sorted); the intersection and the collect run there."""
+    from . import _native
+    files = list(files)
+    t0 = time.time()
+    if len(files) == 1:
+        os.replace(files[0], output)              # shutil.move(files[0], output)
+        return
+    contents = [_read_lines(f) for f in files]
+    geo = None
+    for lines in contents:
+        if lines:
+            f3 = lines[0].split(b",")
+            if len(f3) != 3:
+                raise ValueError("mergeFiles on the device takes the 3-column sorted k-mer files "
+                                 "extractSortedKmers writes")
+            geo = (len(f3[0]), len(f3[1]), len(f3[2]))
+            break
+    if geo is None:
+        open(output, "w").close()
+        return
+    L, D, R = geo
+    _check_geometry(L, D, R)
+    labels = [simplename(f) for f in files]
+    keysets = []
+    for lines in contents:
+        keys = codec.lines_to_keys(lines, L, D, R)
+        if len(keys) > 1 and not np.all(keys[1:] >= keys[:-1]):
+            raise ValueError("k-mer file is not sorted by (left, right, diag)")
+        keysets.append(keys)
+    with _native.Engine(device=device) as eng:
+        eng.set_params(L, D, R, max_bases=max(1, max(len(k) for k in keysets)))
+        for i, keys in enumerate(keysets):
+            eng.load_sorted(i, keys)
+        ids = list(range(len(files)))
+        ncand = eng.intersect(ids, [True] * len(ids), apply_filter=False)
+        records = eng.collect(ids) if ncand else np.empty(0, dtype=_native.RECORD)
+    groups = amplicon.groups_from_records(records, labels, L, D, R)
+    with open(output, "w") as f:
+        for ln in amplicon.merged_lines(groups):
+            f.write(ln + "\n")
+    if verbose:
+        print(f"=> Merged {len(files)} files -> {output} in {prettyTime(time.time() - t0)}", file=sys.stderr)
+
+
+def _parse_merged(path):
+    """merged-file lines -> groups of amplicon.Amplicon (Amplicon.py:298-328,
+    shared.py:350-398, 442-475)."""
+    tag = simplename(path)
+    groups = []
+    for raw in _read_lines(path):
+        f = raw.decode().strip().split(",")
+        if len(f) not in (3, 4):
+            raise ValueError(f"Unrecognised string format : {raw.decode()}")
+        labels = [tag]
+        if len(f) == 4:
+            labels = []
+            for item in f[3].split(";"):
+                item = item.strip()
+                if "(" in item:
+                    name, mult = item.split("(")
+                    labels += [name] * int(mult.strip(")"))
+                else:
+                    labels.append(item)
+        amp = amplicon.Amplicon(f[0], f[1], f[2], labels)
+        if groups and (groups[-1][0].left, groups[-1][0].right) == (amp.left, amp.right):
+            for a in groups[-1]:
+                if a.sequence == amp.sequence:
+                    a.labels = sorted(a.labels + amp.labels)
+                    break
+            else:
+                groups[-1].append(amp)
+        else:
+            groups.append([amp])
+    return groups
+
+
+_BASE_BIT = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def filterAlignments(kmerfile, output, ingroup, device=0):
+    """filterAlignments.py:31-40: keep the groups that have a diagnostic column whose
+    ingroup and outgroup base sets are disjoint (Amplicon.py:495-521).  The host only
+    re-encodes the text (one (in, out) base-set mask pair per group, include/krisp_hip.h
+    kr_cand); the predicate itself is evaluated on the device (kr_cands_merge)."""
+    from . import _native
+    groups = _parse_merged(kmerfile)
+    ingroup = frozenset(ingroup)
+    keep = list(range(len(groups)))
+    if len(ingroup) and groups:
+        D = len(groups[0][0].diag)
+        if D == 0:
+            keep = []                               # diagnosticLength() == 0: no column can pass
+        else:
+            if D > 16:
+                raise UnsupportedGeometry(f"diagnostic length {D} > 16 exceeds the device mask format")
+            cands = np.zeros(len(groups), dtype=_native.CAND)
+            for gi, g in enumerate(groups):
+                im = om = 0
+                for a in g:
+                    m = 0
+                    for c, ch in enumerate(a.diag):
+                        if ch not in _BASE_BIT:
+                            raise fasta.IupacWindowsUnsupported(
+                                f"diagnostic sequence {a.diag!r} holds a non-ACGT letter")
+                        m |= 1 << (4 * c + _BASE_BIT[ch])
+                    for lab in set(a.labels):
+                        if lab in ingroup:
+                            im |= m
+                        else:
+                            om |= m
+                cands[gi] = (gi, im, om)            # prefix = group index: sorted, unique
+            with _native.Engine(device=device) as eng:
+                eng.set_params(1, D, 0, max_bases=64)
+                eng.load_cands(cands)
+                eng.merge_cands(None, apply_filter=True)
+                keep = [int(p) for p in eng.cands()["prefix"]]
+    with open(output, "w") as f:
+        for gi in keep:
+            for a in groups[gi]:
+                f.write(a.line() + "\n")
+
+
+# ----------------------------------------------------------------------------
+# command line (krisp_fasta.py:126-298)
+# ----------------------------------------------------------------------------
+def build_parser():
+    p = argparse.ArgumentParser(description="Find diagnostic alignments for a set of fasta files",
+                                prog="krisp", formatter_class=argparse.RawTextHelpFormatter)
+    p.add_argument("files", nargs="+", type=str, metavar="PATH", help="Fasta file to read. .gz, .bz2")
+    p.add_argument("--outgroup", nargs="*", type=str, default=[], metavar="PATH",
+                   help="Outgroup Fasta files. To be amplified, but not detected")
+    p.add_argument("-c", "--conserved", type=int, metavar="INT",
+                   help="Length of conserved regions on ends of amplicon")
+    p.add_argument("--conserved-left", type=int, metavar="INT",
+                   help="Length of conserved region on left of amplicon")
+    p.add_argument("--conserved-right", type=int, metavar="INT",
+                   help="Length of conserved region on right of amplicon")
+    p.add_argument("-d", "--diagnostic", type=int, metavar="INT", help="Diagnostic region length for amplicon")
+    p.add_argument("-a", "--amplicon", type=int, metavar="INT", help="Total amplicon length")
+    p.add_argument("--omit-soft", action="store_true", help="Omit softmasked nucleotides")
+    p.add_argument("--cores", type=int, default=1, metavar="INT",
+                   help="Total number of processors to utilize. (default: %(default)s)")
+    p.add_argument("--dot-alignment", action="store_true", help="Output as dot-based alignments")
+    p.add_argument("-o", "--out_align", type=str, metavar="PATH",
+                   help="Write results as human-readable alignments to a file. (default: do not write alignment output)")
+    p.add_argument("-s", "--out_csv", type=str, metavar="PATH",
+                   help="Write results to as a CSV (comma-separated value) file. (default: print to screen (stdout))")
+    p.add_argument("-w", "--workdir", type=str, metavar="PATH", help="Work directory to place temporary files")
+    p.add_argument("-p", "--primer3", action=argparse.BooleanOptionalAction,
+                   help="Design primers with Primer3 (not available in this build)")
+    p.add_argument("--tm", type=int, nargs=2, metavar="INT", default=[53, 68])
+    p.add_argument("--gc", type=int, nargs=2, metavar="INT", default=[40, 70])
+    p.add_argument("--amp_size", type=int, nargs=2, metavar="INT", default=[70, 150])
+    p.add_argument("--primer_size", type=int, nargs=2, metavar="INT", default=[25, 35])
+    p.add_argument("--max_sec_tm", type=int, default=40, metavar="INT")
+    p.add_argument("--gc_clamp", type=int, default=1, metavar="INT")
+    p.add_argument("--max_end_gc", type=int, default=4, metavar="INT")
+    p.add_argument("--verbose", action="store_true", help="Print runtime information to sys.stderr")
+    p.add_argument("--device", type=int, default=0, metavar="INT", help="GPU to run on (default: 0)")
+    return p
+
+
+def deduce_geometry(args, parser):
+    """krisp_fasta.py:179-213, same precedence; exits 1 with the same message."""
+    def fail():
+        print("ERROR: Could not deduce input parameters", file=sys.stderr)
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+
+    if args.amplicon is not None:
+        if args.diagnostic is not None:
+            args.conserved = (args.amplicon - args.diagnostic) // 2
+            args.conserved_left = args.conserved_right = args.conserved
+        elif args.conserved is not None:
+            args.diagnostic = args.amplicon - 2 * args.conserved
+            args.conserved_left = args.conserved_right = args.conserved
+        elif args.conserved_left is not None and args.conserved_right is not None:
+            args.diagnostic = args.amplicon - args.conserved_left - args.conserved_right
+        else:
+            fail()
+    elif args.diagnostic is not None:
+        if args.conserved is not None:
+            args.amplicon = args.diagnostic + 2 * args.conserved
+            args.conserved_left = args.conserved_right = args.conserved
+        elif args.conserved_left is not None and args.conserved_right is not None:
+            args.amplicon = args.diagnostic + args.conserved_left + args.conserved_right
+        else:
+            fail()
+    else:
+        fail()
+    return args
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(sys.argv[1:] if argv is None else argv)
+    args = deduce_geometry(args, parser)
+    if args.primer3:
+        print("ERROR: --primer3 needs primer3-py, which this build does not bundle "
+              "(Primer3 design is outside the accelerated path)", file=sys.stderr)
+        sys.exit(2)
+    t0 = time.time()
+    if args.verbose:
+        print("Finding kmer-based diagnostic regions for:", file=sys.stderr)
+        for i, f in enumerate(args.files):
+            print(f"({i}) {f}", file=sys.stderr)
+        print("With this as an outgroup:", file=sys.stderr)
+        for i, f in enumerate(args.outgroup):
+            print(f"({i}) {f}", file=sys.stderr)
+        print(file=sys.stderr)
+    groups, stats = find_regions(args.files, args.outgroup, args.conserved_left, args.conserved_right,
+                                 args.amplicon, omit_soft=args.omit_soft, device=args.device,
+                                 verbose=args.verbose)
+    if args.verbose:
+        print("\nRendering output ... ", file=sys.stderr)
+    ingroup = [simplename(f) for f in args.files] if len(args.outgroup) else None
+    csv_text, align_text = amplicon.render(groups, ingroup, dot=args.dot_alignment)
+    if args.out_csv is not None:
+        with open(args.out_csv, "w") as f:
+            f.write(csv_text)
+    else:
+        sys.stdout.write(csv_text)
+    if args.out_align is not None:
+        with open(args.out_align, "w") as f:
+            f.write(align_text)
+    if args.verbose:
+        print(f"=> Found {len(groups):,} regions in {prettyTime(time.time() - t0)} "
+              f"({stats['kmers']:,} k-mers, device {stats['device_s']:.3f} s)", file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

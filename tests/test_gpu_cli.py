@@ -1,0 +1,170 @@
+"""GPU end-to-end parity: the krisp_amd host layer + libkrisp_hip.so against the golden
+vectors captured from the reference (final text byte for byte, stage files by sha256 /
+canonicalised lines) and the README known answers."""
+import gzip
+import hashlib
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KS = json.load(open(os.path.join(GOLDEN, "kstream_cases.json")))
+FC = json.load(open(os.path.join(GOLDEN, "fasta_cases.json")))
+
+
+def _amplicon(case):
+    a = case.get("main_args", [])
+    if "--amplicon" in a:
+        return int(a[a.index("--amplicon") + 1])
+    return case["L"] + case["D"] + case["R"]
+
+
+PACKABLE = [c for c in FC if _amplicon(c) <= 32 and (_amplicon(c) - c["L"] - c["R"]) <= 16]
+TOO_LONG = [c for c in FC if _amplicon(c) > 32]
+
+
+def _paths(case, tmp_path):
+    if case["name"].startswith("c1_"):
+        return {fn: os.path.join(GOLDEN, "c1", fn) for fn in case["ingroup"] + case["outgroup"]}
+    out = {}
+    for fn, text in case["files"].items():
+        p = tmp_path / fn
+        p.write_text(text)
+        out[fn] = str(p)
+    return out
+
+
+def _run_main(argv):
+    from krisp_amd import krisp_fasta as KF
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        KF.main(argv)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("case", [c for c in PACKABLE if "csv" in c], ids=lambda c: c["name"])
+def test_cli_output_is_byte_identical_to_the_reference(case, tmp_path):
+    paths = _paths(case, tmp_path)
+    argv = [paths[f] for f in case["ingroup"]]
+    if case["outgroup"]:
+        argv += ["--outgroup"] + [paths[f] for f in case["outgroup"]]
+    argv += case["main_args"]
+    if case["omit_soft"]:
+        argv += ["--omit-soft"]
+    if case["dot"]:
+        argv += ["--dot-alignment"]
+    aln = str(tmp_path / "align.txt")
+    csv_stdout = _run_main(argv + ["--cores", "1", "--out_align", aln])
+    assert csv_stdout == case["csv"]
+    assert open(aln).read() == case["align"]
+    csvp = str(tmp_path / "out.csv")
+    assert _run_main(argv + ["--cores", "4", "--out_csv", csvp]) == ""
+    assert open(csvp).read() == case["csv"]
+
+
+@pytest.mark.parametrize("case", PACKABLE, ids=lambda c: c["name"])
+def test_stage_functions_match_reference_intermediates(case, tmp_path):
+    from krisp_amd import krisp_fasta as KF
+    from krisp_amd import fasta
+    L, D, R = case["L"], case["D"], case["R"]
+    k = _amplicon(case)
+    paths = _paths(case, tmp_path)
+    files = case["ingroup"] + case["outgroup"]
+    kfiles = []
+    iupac = "csv" not in case
+    for fn in files:
+        out = str(tmp_path / f"{KF.basename(fn)}.{k}mers")
+        if iupac:
+            # the reference keeps IUPAC k-mers; the 2-bit device path refuses loudly
+            try:
+                KF.extractSortedKmers(paths[fn], L, R, k, out, "80%", 1, False, case["omit_soft"])
+            except fasta.IupacWindowsUnsupported:
+                return
+        else:
+            KF.extractSortedKmers(paths[fn], L, R, k, out, "80%", 1, False, case["omit_soft"])
+        data = open(out, "rb").read()
+        assert data.count(b"\n") == case["sorted"][fn]["lines"]
+        assert hashlib.sha256(data).hexdigest() == case["sorted"][fn]["sha256"], fn
+        kfiles.append(out)
+    merged = str(tmp_path / "merged_file.txt")
+    KF.mergeFiles(list(kfiles), merged, 1, str(tmp_path), False)
+    assert sorted(open(merged).read().split("\n")[:-1]) == case["merged_canon"]
+    if "filtered_canon" in case:
+        filt = str(tmp_path / "filtered.txt")
+        KF.filterAlignments(merged, filt, frozenset(KF.simplename(f) for f in case["ingroup"]))
+        assert sorted(open(filt).read().split("\n")[:-1]) == case["filtered_canon"]
+
+
+@pytest.mark.parametrize("case", TOO_LONG, ids=lambda c: c["name"])
+def test_amplicons_longer_than_32_fail_loudly(case, tmp_path):
+    from krisp_amd import krisp_fasta as KF
+    paths = _paths(case, tmp_path)
+    with pytest.raises(KF.UnsupportedGeometry):
+        KF.find_regions([paths[f] for f in case["ingroup"]], [paths[f] for f in case["outgroup"]],
+                        case["L"], case["R"], _amplicon(case), omit_soft=case["omit_soft"])
+
+
+def _geo(kwargs):
+    from krisp_amd.kstream import kstream
+    try:
+        return kstream(**kwargs).device_geometry()
+    except ValueError:
+        return None
+
+
+@pytest.mark.parametrize("case", [c for c in KS if _geo(c["kwargs"]) is not None], ids=lambda c: c["name"])
+def test_kstream_accelerated_combination(case, tmp_path):
+    from krisp_amd import fasta
+    from krisp_amd.kstream import kstream
+    src = case["seqs"]
+    if case["file_text"] is not None:
+        src = str(tmp_path / case["fname"])
+        opener = gzip.open if case["fname"].endswith(".gz") else open
+        with opener(src, "wt") as f:
+            f.write(case["file_text"])
+    ks = kstream(**case["kwargs"])
+    has_iupac = any(ch in "RYKMSWBDHVrykmswbdhv" for ln in case.get("out", []) for ch in ln)
+    if "raises" in case:
+        with pytest.raises(Exception) as ei:
+            list(ks(src))
+        assert type(ei.value).__name__ == case["raises"]
+        return
+    if has_iupac:
+        with pytest.raises(fasta.IupacWindowsUnsupported):
+            list(ks(src))
+        return
+    if case["use_write"]:
+        out = str(tmp_path / "out.txt")
+        assert ks.write(out, src) == case["count"]
+        assert open(out).read().split("\n")[:-1] == case["out"]
+    else:
+        assert list(ks(src)) == case["out"]
+
+
+def test_readme_known_answers_on_the_gpu(tmp_path):
+    d = os.path.join(GOLDEN, "c1")
+    ing = [f"{d}/ingroup{i}.fasta.gz" for i in (0, 1)]
+    outg = [f"{d}/outgroup{i}.fasta.gz" for i in (0, 1, 2)]
+    aln = str(tmp_path / "a.txt")
+    csv = _run_main(ing + ["--outgroup"] + outg + ["--conserved-left", "25", "--conserved-right", "2",
+                                                   "--diagnostic", "1", "--out_align", aln])
+    assert csv == ("left_seq,diag_seq,right_seq\n"
+                   "CGACAAGATACTCTCGCAGCTTGGT,M,AG\n"
+                   "TGACGCAGATCATCCCGCGCTTACT,K,AC\n")       # README.md:121-123 (its 'K,A' is a typo)
+    assert open(aln).read() == (
+        "CGACAAGATACTCTCGCAGCTTGGTCAG : ingroup0\n"
+        "CGACAAGATACTCTCGCAGCTTGGTAAG : ingroup1\n"
+        "CGACAAGATACTCTCGCAGCTTGGTGAG : outgroup0;outgroup1;outgroup2\n"
+        "                        {#}\n\n"
+        "TGACGCAGATCATCCCGCGCTTACTGAC : ingroup0\n"
+        "TGACGCAGATCATCCCGCGCTTACTTAC : ingroup1\n"
+        "TGACGCAGATCATCCCGCGCTTACTCAC : outgroup0;outgroup1;outgroup2\n"
+        "                        {#}\n\n")
+    single = _run_main([ing[0], "--conserved", "14", "--diagnostic", "0"])
+    assert single.startswith("left_seq,diag_seq,right_seq\n") and single.count("\n") > 1000

@@ -1,0 +1,211 @@
+"""CPU tests of the host layer: ingest, codecs, rendering, option routing, the C ABI
+surface.  No GPU: device results are stood in for by the packed-key oracle's records."""
+import ctypes
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from krisp_amd import _native, amplicon, codec, fasta
+from krisp_amd import krisp_fasta as KF
+from krisp_amd.kstream import kstream
+from oracle import kmer_oracle as K
+from oracle import krisp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KS = json.load(open(os.path.join(GOLDEN, "kstream_cases.json")))
+FC = json.load(open(os.path.join(GOLDEN, "fasta_cases.json")))
+
+
+def _src(case, tmp_path):
+    if case["file_text"] is None:
+        return case["seqs"]
+    p = str(tmp_path / case["fname"])
+    opener = gzip.open if case["fname"].endswith(".gz") else open
+    with opener(p, "wt") as f:
+        f.write(case["file_text"])
+    return p
+
+
+@pytest.mark.parametrize("case", KS, ids=[c["name"] for c in KS])
+def test_read_records_matches_reference_reader(case, tmp_path):
+    src = _src(case, tmp_path)
+    want = O.parse_records(O.read_lines(src), one_shot=True) if isinstance(src, str) \
+        else O.parse_records(src, one_shot=False)
+    got = [r.decode() for r in fasta.read_records(src)]
+    assert got == want
+
+
+def _safe_geometry(kwargs):
+    try:
+        return kstream(**kwargs).device_geometry()
+    except ValueError:
+        return None
+
+
+@pytest.mark.parametrize("case", [c for c in KS if "raises" in c or _safe_geometry(c["kwargs"]) is None],
+                         ids=lambda c: c["name"])
+def test_kstream_host_chain_matches_reference(case, tmp_path):
+    src = _src(case, tmp_path)
+    if "raises" in case:
+        if case["raises"] == "ValueError":
+            with pytest.raises(ValueError):
+                kstream(**case["kwargs"])
+            return
+        ks = kstream(**case["kwargs"])
+        if ks.device_geometry() is not None:
+            pytest.skip("accelerated combination: covered by the gpu tests")
+        with pytest.raises(Exception) as ei:
+            list(ks(src))
+        assert type(ei.value).__name__ == case["raises"]
+        return
+    ks = kstream(**case["kwargs"])
+    if case["use_write"]:
+        out = str(tmp_path / "out.txt")
+        n = ks.write(out, src)
+        lines = open(out).read().split("\n")[:-1]
+        assert n == case["count"]
+    else:
+        lines = list(ks(src))
+    assert lines == case["out"]
+
+
+def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
+    base = dict(kmers=28, complements=True, disallow="Nn", mapsoft=True, split=[25, -2], sort=True,
+                sortcols=[0, 2])
+    assert kstream(**base).device_geometry() == (25, 1, 2)
+    assert kstream(**dict(base, split=[25, 0])).device_geometry() == (25, 0, 3)     # R = 0 quirk
+    assert kstream(**dict(base, mapsoft=False, omitsoft=True)).device_geometry() == (25, 1, 2)
+    for change in (dict(kmers=33, split=[30, -2]), dict(complements=False), dict(disallow="N"),
+                   dict(mapsoft=False), dict(sort=False), dict(sortcols=None), dict(sortcols=[0]),
+                   dict(allow="ACGT"), dict(expandiupac=True), dict(split=None), dict(kmers=[28, 29])):
+        assert kstream(**dict(base, **change)).device_geometry() is None, change
+
+
+def test_codec_roundtrip_and_oracle_agreement():
+    rng = np.random.default_rng(3)
+    for (L, D, R) in [(25, 1, 2), (3, 1, 2), (16, 0, 16), (0, 2, 3), (10, 16, 6), (5, 0, 3)]:
+        k = L + D + R
+        keys = (rng.integers(0, 1 << 62, size=200, dtype=np.uint64) << np.uint64(2)) & codec_topmask(k)
+        blob = codec.keys_to_lines_bytes(keys, L, D, R)
+        lines = blob.split(b"\n")[:-1]
+        assert [l.decode() for l in lines] == K.keys_to_lines(keys, L, D, R)
+        assert np.array_equal(codec.lines_to_keys(lines, L, D, R), keys)
+    assert codec.effective_geometry(3, 2, 0) == (3, 0, 2)
+    assert codec.effective_geometry(3, 0, 0) == (3, 0, 0)
+
+
+def codec_topmask(k):
+    return np.uint64((~0 << (64 - 2 * k)) & 0xFFFFFFFFFFFFFFFF)
+
+
+PACKABLE = [c for c in FC if c["L"] + c["D"] + c["R"] <= 32 and c["D"] <= 16 and "csv" in c]
+
+
+def _paths(case, tmp_path):
+    if case["name"].startswith("c1_"):
+        return {fn: os.path.join(GOLDEN, "c1", fn) for fn in case["ingroup"] + case["outgroup"]}
+    out = {}
+    for fn, text in case["files"].items():
+        p = tmp_path / fn
+        p.write_text(text)
+        out[fn] = str(p)
+    return out
+
+
+@pytest.mark.parametrize("case", PACKABLE, ids=[c["name"] for c in PACKABLE])
+def test_render_from_records_matches_reference_text(case, tmp_path):
+    """host glue only: (key, genome, count) records (here from the oracle) -> final text."""
+    L, D, R = case["L"], case["D"], case["R"]
+    k = L + D + R
+    if "--amplicon" in case["main_args"]:
+        k = int(case["main_args"][case["main_args"].index("--amplicon") + 1])
+    Le, De, Re = codec.effective_geometry(L, k - L - R, R)
+    paths = _paths(case, tmp_path)
+    files = case["ingroup"] + case["outgroup"]
+    keys = []
+    for fn in files:
+        recs = fasta.read_records(paths[fn])
+        keys.append(K.sorted_keys(fasta.to_bases(recs).tobytes(), Le, De, Re, omit=case["omit_soft"]))
+    labels = [KF.simplename(f) for f in files]
+    ing = frozenset(KF.simplename(f) for f in case["ingroup"])
+    flags = [lab in ing for lab in labels]
+    do_filter = k > L + R
+    if do_filter and De == 0:
+        groups = []
+    else:
+        cands = K.intersect(keys, flags, Le, De, Re, apply_filter=do_filter)
+        recs = K.collect(keys, cands, Le, De, Re)
+        groups = amplicon.groups_from_records(recs, labels, Le, De, Re)
+    ingroup = [KF.simplename(f) for f in case["ingroup"]] if case["outgroup"] else None
+    csv, align = amplicon.render(groups, ingroup, dot=case["dot"])
+    assert csv == case["csv"]
+    assert align == case["align"]
+    want = case["filtered_canon"] if "filtered_canon" in case else case["merged_canon"]
+    assert sorted(amplicon.merged_lines(groups)) == want
+
+
+def test_check_special_semantics():
+    b = lambda s: np.frombuffer(s.encode(), dtype=np.uint8)          # noqa: E731
+    fasta.check_special(b("ACGTNNacgt\nACGT"), 4, False)              # plain: nothing to do
+    with pytest.raises(KeyError):
+        fasta.check_special(b("ACGXAC"), 4, False)
+    fasta.check_special(b("ACGxAC"), 4, True)                         # lower-case window dropped first
+    with pytest.raises(KeyError):
+        fasta.check_special(b("ACG-AC"), 4, True)                     # isupper() ignores '-'
+    fasta.check_special(b("ACX\nGTAC"), 4, False)                     # no window spans the separator
+    with pytest.raises(fasta.IupacWindowsUnsupported):
+        fasta.check_special(b("ACGTRACGT"), 4, False)
+    fasta.check_special(b("ACNRNAC"), 3, False)                       # every R window also holds N
+
+
+def test_deduce_geometry_matches_reference_rules():
+    p = KF.build_parser()
+    for argv, want in [(["f", "--amplicon", "100", "--conserved", "30"], (30, 40, 30, 100)),
+                       (["f", "--amplicon", "100", "--diagnostic", "41"], (29, 41, 29, 100)),
+                       (["f", "--conserved-left", "25", "--conserved-right", "2", "--diagnostic", "1"], (25, 1, 2, 28)),
+                       (["f", "-c", "30", "-d", "0"], (30, 0, 30, 60)),
+                       (["f", "-a", "50", "--conserved-left", "10", "--conserved-right", "12"], (10, 28, 12, 50))]:
+        a = KF.deduce_geometry(p.parse_args(argv), p)
+        assert (a.conserved_left, a.diagnostic, a.conserved_right, a.amplicon) == want
+        kw = {k: getattr(p.parse_args(argv), k) for k in
+              ("conserved", "conserved_left", "conserved_right", "diagnostic", "amplicon")}
+        assert O.deduce_ldr(**kw) == want
+    with pytest.raises(SystemExit) as ei:
+        KF.deduce_geometry(p.parse_args(["f", "-c", "5"]), p)
+    assert ei.value.code == 1
+
+
+def test_names():
+    for fn in ["ingroup0.fasta.gz", "outX.v1.fna", "a.b.c.fa.bz2", "/x/y/in.fasta", "plain"]:
+        assert KF.basename(fn) == O.basename(fn)
+        assert KF.simplename(fn) == O.simplename(fn)
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    """No compute without a GPU: only load + symbol table + the failure mode of kr_create."""
+    header = open(os.path.join(ROOT, "include", "krisp_hip.h")).read()
+    declared = set(re.findall(r"\b(kr_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = _native.load()
+    bound = {name for name, _, _ in _native.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name), name
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (kr_[a-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libkrisp_hip.so")
+    with pytest.raises(_native.KrispHipError):
+        _native.load()
+    with pytest.raises(_native.KrispHipError):
+        _native.Engine()
