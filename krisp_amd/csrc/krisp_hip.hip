@@ -184,7 +184,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* lds_waves /* >= 17 u3
 // cursor offset inside bucket d), then a scan over d gives the bucket bases.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32* __restrict__ base1,
-                                                 u32* __restrict__ tp, u32* __restrict__ tiled1) {
+                                                 u32* __restrict__ tp, uint2* __restrict__ tiledesc) {
     __shared__ u32 waves[17];
     const u32 d = threadIdx.x;
     u32 run = 0;
@@ -202,13 +202,17 @@ __global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32
     u32 ex = block_excl_scan(run, waves, total);
     base1[d] = ex;
     if (d == 0) base1[256] = total;
-    // pass-2 tiles never straddle a bucket: tp[d] = first tile of bucket d, tiled1[tile] = its bucket
+    // pass-2 tiles never straddle a bucket: tp[d] = first tile of bucket d,
+    // tiledesc[tile] = its key range (pre-zeroed: unused tiles are empty)
     const u32 ntile = (run + P2_TILE - 1) / P2_TILE;
     u32 ttotal;
     u32 t0 = block_excl_scan(ntile, waves, ttotal);
     tp[d] = t0;
     if (d == 0) tp[256] = ttotal;
-    for (u32 t = 0; t < ntile; t++) tiled1[t0 + t] = d;
+    for (u32 t = 0; t < ntile; t++) {
+        u32 ts = ex + t * P2_TILE;
+        tiledesc[t0 + t] = make_uint2(ts, min(ex + run, ts + P2_TILE));
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -320,16 +324,14 @@ __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes
 //   k_scatter2 per tile: rank, scan, stage digit-sorted in LDS, coalesced runs out
 // No global atomics, any number of workgroups per CU.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(P2_T) void k_hist2(const u64* __restrict__ src, const u32* __restrict__ base1,
-                                               const u32* __restrict__ tp, const u32* __restrict__ tiled1,
+__global__ __launch_bounds__(P2_T) void k_hist2(const u64* __restrict__ src, const uint2* __restrict__ tiledesc,
                                                u32* __restrict__ tilehist, int b) {
     __shared__ u32 h[1024];
     const u32 tile = blockIdx.x;
-    if (tile >= tp[256]) return;
+    const uint2 td = tiledesc[tile];
+    const u32 s = td.x, e = td.y;
+    if (s >= e) return;
     const u32 nb2 = 1u << (b - 8);
-    const u32 d1 = tiled1[tile];
-    const u32 s = base1[d1] + (tile - tp[d1]) * P2_TILE;
-    const u32 e = min(base1[d1 + 1], s + P2_TILE);
     const int rb = 64 - b;
     for (u32 i = threadIdx.x; i < nb2; i += P2_T) h[i] = 0;
     __syncthreads();
@@ -372,20 +374,18 @@ __global__ __launch_bounds__(1024) void k_scan2(u32* __restrict__ tilehist, cons
 }
 
 __global__ __launch_bounds__(P2_T) void k_scatter2(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                   const u32* __restrict__ base1, const u32* __restrict__ tp,
-                                                   const u32* __restrict__ tiled1,
+                                                   const uint2* __restrict__ tiledesc,
                                                    const u32* __restrict__ tilehist, int b) {
     __shared__ __attribute__((aligned(16))) u64 stage[P2_TILE];
     __shared__ u32 cnt[1024];
     __shared__ u32 delta[1024];
     __shared__ u32 waves[17];
     const u32 tile = blockIdx.x;
-    if (tile >= tp[256]) return;
+    const uint2 td = tiledesc[tile];
+    const u32 s = td.x, e = td.y;
+    if (s >= e) return;
     const u32 tid = threadIdx.x;
     const u32 nb2 = 1u << (b - 8);
-    const u32 d1 = tiled1[tile];
-    const u32 s = base1[d1] + (tile - tp[d1]) * P2_TILE;
-    const u32 e = min(base1[d1 + 1], s + P2_TILE);
     const int rb = 64 - b;
     u64 key[P2_KPT];
     u32 r[P2_KPT];
@@ -444,6 +444,18 @@ __global__ void k_chunk_bounds(const u32* __restrict__ off, u32 nb, u32* __restr
     for (u32 j = jlo; j <= jhi; j++) chunkstart[j] = f;
 }
 
+// chunk descriptors {first key, end key, first bucket, end bucket}: one 16-byte load per chunk
+// instead of a chain of three dependent ones
+__global__ void k_chunk_desc(const u32* __restrict__ off, const u32* __restrict__ chunkstart, u32 nchunks,
+                             uint4* __restrict__ desc) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nchunks) return;
+    u32 lo = chunkstart[j], hi = chunkstart[j + 1];
+    uint4 d = make_uint4(0, 0, 0, 0);
+    if (lo < hi) d = make_uint4(off[lo], off[hi], lo, hi);
+    desc[j] = d;
+}
+
 // fine bucket offsets of an already sorted key array: off[f] = lower_bound(f << rb)
 __global__ void k_offsets_from_sorted(const u64* __restrict__ keys, u32 n, u32 nb, int rb, u32* __restrict__ off) {
     u32 f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,120 +482,144 @@ __device__ __forceinline__ u32 cnt16_get(const u32* c, u32 i) {
     return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
 }
 
+__device__ __forceinline__ void ls_load(const u64* __restrict__ keys, uint4 d, u64 (&k)[LS_PER]) {
+    const u32 m = min(d.y - d.x, LS_CAP);
+#pragma unroll
+    for (int i = 0; i < (int)LS_PER; i++) {
+        u32 p = threadIdx.x + i * LS_THREADS;
+        k[i] = p < m ? keys[d.x + p] : 0;
+    }
+}
+
+// Persistent: grid = resident workgroups; each walks chunks j, j+G, ... with the NEXT chunk's
+// keys (and the descriptor after that) already in flight while the current one is sorted.
 __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys,
                                                           const u32* __restrict__ off,
-                                                          const u32* __restrict__ chunkstart, int b,
+                                                          const uint4* __restrict__ desc, u32 nchunks, int b,
                                                           u32* __restrict__ ovf_count,
-                                                          uint2* __restrict__ ovf_list) {
+                                                          uint2* __restrict__ ovf_list, int dbg) {
     __shared__ __attribute__((aligned(16))) u64 S[LS_CAP];
     __shared__ u32 cnt[LS_NB / 2];
     __shared__ u32 waves[17];
     __shared__ u32 s_maxbin;
     const u32 tid = threadIdx.x;
-    u32 lo = chunkstart[blockIdx.x], hi = chunkstart[blockIdx.x + 1];
-    if (lo >= hi) return;
-    u32 s = off[lo], e = off[hi];
-    u32 m = e - s;
-    if (m > LS_CAP) {
-        u32 last = hi - 1;
-        if (tid == 0) {
-            u32 idx = atomicAdd(ovf_count, 1u);
-            if (idx < OVF_MAX) ovf_list[idx] = make_uint2(off[last], e);
-        }
-        hi = last;
-        e = off[hi];
-        m = e - s;
-        if (m == 0 || lo >= hi) return;
-    }
+    const u32 G = gridDim.x;
     const int rb = 64 - b;
-    const u32 nbk = hi - lo;
-    const int clog = nbk <= 1 ? 0 : 32 - __clz((int)(nbk - 1));
-    const int sh = rb + clog - 12;
-    const u64 keylo = (u64)lo << rb;
-
-    for (u32 i = tid; i < LS_NB / 2; i += LS_THREADS) cnt[i] = 0;
-    if (tid == 0) s_maxbin = 0;
-    __syncthreads();
-
-    u64 key[LS_PER];
-    u32 sub[LS_PER], r[LS_PER];
-#pragma unroll
-    for (int i = 0; i < (int)LS_PER; i++) {
-        u32 p = tid + i * LS_THREADS;
-        if (p < m) {
-            key[i] = keys[s + p];
-            sub[i] = (u32)((key[i] - keylo) >> sh);
-            u32 old = atomicAdd(&cnt[sub[i] >> 1], (sub[i] & 1) ? 0x10000u : 1u);
-            r[i] = (sub[i] & 1) ? (old >> 16) : (old & 0xFFFFu);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32 j = blockIdx.x;
+    uint4 dc = j < nchunks ? desc[j] : zero4;
+    uint4 dn = j + G < nchunks ? desc[j + G] : zero4;
+    u64 key[LS_PER], nkey[LS_PER];
+    ls_load(keys, dc, key);
+    for (; j < nchunks; j += G) {
+        const uint4 dnn = j + 2 * G < nchunks ? desc[j + 2 * G] : zero4;
+        ls_load(keys, dn, nkey);
+        u32 s = dc.x, e = dc.y, lo = dc.z, hi = dc.w;
+        u32 m = e - s;
+        if (m > LS_CAP) {           // the chunk's last bucket is oversized: global fallback sorts it
+            u32 last = hi - 1;
+            u32 ls = off[last];
+            if (tid == 0) {
+                u32 idx = atomicAdd(ovf_count, 1u);
+                if (idx < OVF_MAX) ovf_list[idx] = make_uint2(ls, e);
+            }
+            hi = last;
+            e = ls;
+            m = e - s;
         }
-    }
-    __syncthreads();
-    // exclusive scan of the 4096 16-bit counters: thread t owns LS_WPT consecutive words
-    {
-        u32 w[LS_WPT];
-        u32 sum = 0, mx = 0;
+        if (m > 0) {
+            const u32 nbk = hi - lo;
+            const int clog = nbk <= 1 ? 0 : 32 - __clz((int)(nbk - 1));
+            const int sh = rb + clog - 12;
+            const u64 keylo = (u64)lo << rb;
+            for (u32 i = tid; i < LS_NB / 2; i += LS_THREADS) cnt[i] = 0;
+            if (tid == 0) s_maxbin = 0;
+            __syncthreads();
+            u32 sub[LS_PER], r[LS_PER];
 #pragma unroll
-        for (int q = 0; q < LS_WPT; q++) {
-            w[q] = cnt[tid * LS_WPT + q];
-            u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
-            sum += a + c2;
-            mx = max(mx, max(a, c2));
-        }
-        if (mx > LS_BIN_LIMIT) atomicMax(&s_maxbin, mx);
-        u32 total;
-        u32 ex = block_excl_scan(sum, waves, total);
+            for (int i = 0; i < (int)LS_PER; i++) {
+                u32 p = tid + i * LS_THREADS;
+                if (p < m) {
+                    sub[i] = (u32)((key[i] - keylo) >> sh);
+                    u32 old = atomicAdd(&cnt[sub[i] >> 1], (sub[i] & 1) ? 0x10000u : 1u);
+                    r[i] = (sub[i] & 1) ? (old >> 16) : (old & 0xFFFFu);
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the 4096 16-bit counters: thread t owns LS_WPT consecutive words
+            {
+                u32 w[LS_WPT];
+                u32 sum = 0, mx = 0;
 #pragma unroll
-        for (int q = 0; q < LS_WPT; q++) {
-            u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
-            u32 lo16 = ex;
-            ex += a;
-            u32 hi16 = ex;
-            ex += c2;
-            cnt[tid * LS_WPT + q] = lo16 | (hi16 << 16);
-        }
-    }
-    __syncthreads();
+                for (int q = 0; q < LS_WPT; q++) {
+                    w[q] = cnt[tid * LS_WPT + q];
+                    u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
+                    sum += a + c2;
+                    mx = max(mx, max(a, c2));
+                }
+                if (mx > LS_BIN_LIMIT) atomicMax(&s_maxbin, mx);
+                u32 total;
+                u32 ex = block_excl_scan(sum, waves, total);
 #pragma unroll
-    for (int i = 0; i < (int)LS_PER; i++) {
-        u32 p = tid + i * LS_THREADS;
-        if (p < m) S[cnt16_get(cnt, sub[i]) + r[i]] = key[i];
-    }
-    __syncthreads();
-    if (s_maxbin <= LS_BIN_LIMIT) {
+                for (int q = 0; q < LS_WPT; q++) {
+                    u32 a = w[q] & 0xFFFFu, c2 = w[q] >> 16;
+                    u32 lo16 = ex;
+                    ex += a;
+                    u32 hi16 = ex;
+                    ex += c2;
+                    cnt[tid * LS_WPT + q] = lo16 | (hi16 << 16);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < (int)LS_PER; i++) {
+                u32 p = tid + i * LS_THREADS;
+                if (p < m) S[cnt16_get(cnt, sub[i]) + r[i]] = key[i];
+            }
+            __syncthreads();
+            if (s_maxbin <= LS_BIN_LIMIT) {
 #pragma unroll 2
-        for (int i = 0; i < (int)LS_PER; i++) {
-            u32 p = tid + i * LS_THREADS;
-            if (p < m) {
-                u64 kk = S[p];
-                u32 sb = (u32)((kk - keylo) >> sh);
-                u32 b0 = cnt16_get(cnt, sb);
-                u32 b1 = sb + 1 < LS_NB ? cnt16_get(cnt, sb + 1) : m;
-                u32 rank = b0;
-                for (u32 q = b0; q < b1; q++) {
-                    u64 kq = S[q];
-                    rank += (kq < kk) || (kq == kk && q < p);
+                for (int i = 0; i < (int)LS_PER; i++) {
+                    u32 p = tid + i * LS_THREADS;
+                    if (p < m) {
+                        u64 kk = S[p];
+                        u32 sb = (u32)((kk - keylo) >> sh);
+                        u32 b0 = cnt16_get(cnt, sb);
+                        u32 b1 = sb + 1 < LS_NB ? cnt16_get(cnt, sb + 1) : m;
+                        u32 rank = b0;
+                        if (!(dbg & 8))
+                            for (u32 q = b0; q < b1; q++) {
+                                u64 kq = S[q];
+                                rank += (kq < kk) || (kq == kk && q < p);
+                            }
+                        keys[s + rank] = kk;
+                    }
                 }
-                keys[s + rank] = kk;
-            }
-        }
-    } else {
-        u32 np = 1;
-        while (np < m) np <<= 1;
-        for (u32 p = m + tid; p < np; p += LS_THREADS) S[p] = ~0ull;
-        __syncthreads();
-        for (u32 kk = 2; kk <= np; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 t = tid; t < np / 2; t += LS_THREADS) {
-                    u32 i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    u32 i1 = i0 | j;
-                    bool up = (i0 & kk) == 0;
-                    u64 a = S[i0], c2 = S[i1];
-                    if ((a > c2) == up) { S[i0] = c2; S[i1] = a; }
-                }
+            } else {
+                u32 np = 1;
+                while (np < m) np <<= 1;
+                for (u32 p = m + tid; p < np; p += LS_THREADS) S[p] = ~0ull;
                 __syncthreads();
+                for (u32 kk = 2; kk <= np; kk <<= 1) {
+                    for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                        for (u32 t = tid; t < np / 2; t += LS_THREADS) {
+                            u32 i0 = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                            u32 i1 = i0 | jj;
+                            bool up = (i0 & kk) == 0;
+                            u64 a = S[i0], c2 = S[i1];
+                            if ((a > c2) == up) { S[i0] = c2; S[i1] = a; }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (u32 p = tid; p < m; p += LS_THREADS) keys[s + p] = S[p];
             }
+            __syncthreads();      // S / cnt are reused by the next chunk
         }
-        for (u32 p = tid; p < m; p += LS_THREADS) keys[s + p] = S[p];
+        dc = dn;
+        dn = dnn;
+#pragma unroll
+        for (int i = 0; i < (int)LS_PER; i++) key[i] = nkey[i];
     }
 }
 
@@ -656,7 +692,7 @@ struct IsectArgs {
     u32 ingroup_bits;
     int n;
     int anchor;
-    const u32* chunkstart;
+    const uint4* chunkdesc;
     kr_cand* tmp;
     u32* chunkcnt;
     int apply_filter;
@@ -732,13 +768,13 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
     __shared__ u32 mpref[65];
     __shared__ u32 sstart[MAXG], send[MAXG];
     const u32 tid = threadIdx.x;
-    const u32 lo = a.chunkstart[blockIdx.x], hi = a.chunkstart[blockIdx.x + 1];
-    if (lo >= hi) {
+    const uint4 cd = a.chunkdesc[blockIdx.x];
+    const u32 sa = cd.x, ea = cd.y;
+    if (sa >= ea) {
         if (tid == 0) a.chunkcnt[blockIdx.x] = 0;
         return;
     }
     const u64* KA = a.keys[a.anchor];
-    const u32 sa = a.off[a.anchor][lo], ea = a.off[a.anchor][hi];
     const u32 full = a.n >= 32 ? 0xFFFFFFFFu : ((1u << a.n) - 1);
     const int LR = g.L + g.R;
     u32 nout = 0;
@@ -871,12 +907,12 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
 
 // ----------------------------------------------------------------------------
 // K6b  dense, ordered candidate list from the per-chunk runs
-__global__ void k_gather_cands(const kr_cand* __restrict__ tmp, const u32* __restrict__ chunkstart,
-                               const u32* __restrict__ offA, const u32* __restrict__ chunkcnt,
+__global__ void k_gather_cands(const kr_cand* __restrict__ tmp, const uint4* __restrict__ chunkdesc,
+                               const u32* __restrict__ chunkcnt,
                                const u32* __restrict__ chunkpos, kr_cand* __restrict__ out) {
     u32 n = chunkcnt[blockIdx.x];
     if (n == 0) return;
-    u64 src = offA[chunkstart[blockIdx.x]];
+    u64 src = chunkdesc[blockIdx.x].x;
     u32 dst = chunkpos[blockIdx.x];
     for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[dst + i] = tmp[src + i];
 }
@@ -974,22 +1010,33 @@ struct Genome {
     size_t n_bases = 0;
     u64 nwords = 0;       // ceil(n/32)
     u64 nmax = 0;         // upper bound of the key count
-    DevBuf bases, keys, off, chunkstart, ovf;   // ovf: u32 count @0, uint2 segments @16
+    DevBuf bases, keys, off, chunkstart, chunkdesc, ovf;   // ovf: u32 count @0, uint2 segments @16
     u32 nchunks = 0;
     bool uploaded = false, sorted = false, finalized = false;
     int64_t count = -1;
 };
 
+// one sort "lane" = a stream + the scratch one genome sort needs; consecutive genome sorts
+// go to different lanes so that their (latency / barrier bound) kernels overlap on the GPU
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    DevBuf codes, bad, partial8, base1, tmpkeys, tp, tiledesc, tilehist;
+};
+#define MAX_LANES 8
+
 struct kr_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // main stream = lanes[0].stream
+    Lane lanes[MAX_LANES];
+    int nlanes = 2, next_lane = 0;
     size_t budget = 0, used = 0;
     bool have_params = false;
     Geom g{};
     size_t max_bases = 0;
     std::map<int, Genome> genomes;
-    // scratch shared by all genome sorts
-    DevBuf codes, bad, partial8, base1, tmpkeys, tp, tiled1, tilehist;
+    int ls_grid = 768;     // resident k_localsort workgroups (set from the occupancy query)
     // candidates / records
     DevBuf candA, candB, chunkcnt, chunkpos, flags, blockcnt, blockpos, other, records, nrec;
     int64_t ncand = -1;
@@ -1004,6 +1051,7 @@ struct kr_ctx {
     double stage_ms[KR_ST_COUNT] = {0};
     int64_t stage_n[KR_ST_COUNT] = {0};
     int64_t fallback_launches = 0, overflow_segments = 0;
+    int dbg = 0;   // KR_DBG ablation switches (benchmark diagnostics only)
 };
 
 static int fail(kr_ctx* c, int code, const char* fmt, ...) {
@@ -1029,7 +1077,7 @@ static int ensure(kr_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes < 16) bytes = 16;
     if (b.bytes >= bytes) return KR_OK;
     if (b.p) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)hipDeviceSynchronize();
         (void)hipFree(b.p);
         c->used -= b.bytes;
         b.p = nullptr;
@@ -1057,7 +1105,8 @@ struct StageScope {
     kr_ctx* c;
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
-    StageScope(kr_ctx* c_, int st) : c(c_), stage(st) {
+    hipStream_t stream;
+    StageScope(kr_ctx* c_, int st, hipStream_t s_ = nullptr) : c(c_), stage(st), stream(s_ ? s_ : c_->stream) {
         c->stage_n[st]++;
         if (!c->stage_on) return;
         auto get = [&]() {
@@ -1068,11 +1117,11 @@ struct StageScope {
         };
         a = get();
         b = get();
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, stream);
     }
     ~StageScope() {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, stream);
         c->pending.push_back({a, b, stage});
     }
 };
@@ -1086,6 +1135,18 @@ static void resolve_stages(kr_ctx* c) {
         c->pool.push_back(p.b);
     }
     c->pending.clear();
+}
+
+// make the main stream wait for every lane that has sorts in flight
+static int join_lanes(kr_ctx* c) {
+    for (int i = 1; i < c->nlanes; i++) {
+        Lane& ln = c->lanes[i];
+        if (!ln.pending) continue;
+        HIPCHK(c, hipEventRecord(ln.done, ln.stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ln.done, 0));
+        ln.pending = false;
+    }
+    return KR_OK;
 }
 
 extern "C" {
@@ -1109,35 +1170,61 @@ kr_ctx* kr_create(int device, size_t hbm_budget_bytes) {
     kr_ctx* c = new kr_ctx();
     c->device = device;
     c->budget = hbm_budget_bytes;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->t0) != hipSuccess ||
-        hipEventCreate(&c->t1) != hipSuccess) {
+    {
+        const char* e = getenv("KR_DBG");
+        c->dbg = e ? atoi(e) : 0;
+        int ncu = 256, per = 3;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_localsort, LS_THREADS, 0) != hipSuccess || per < 1)
+            per = 2;
+        c->ls_grid = ncu * per;
+    }
+    {
+        const char* e = getenv("KR_LANES");
+        int nl = e ? atoi(e) : 2;
+        c->nlanes = nl < 1 ? 1 : (nl > MAX_LANES ? MAX_LANES : nl);
+    }
+    bool ok = hipEventCreate(&c->t0) == hipSuccess && hipEventCreate(&c->t1) == hipSuccess;
+    for (int i = 0; ok && i < c->nlanes; i++)
+        ok = hipStreamCreate(&c->lanes[i].stream) == hipSuccess &&
+             hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         g_last_error = "stream / event creation failed";
         delete c;
         return nullptr;
     }
+    c->stream = c->lanes[0].stream;
     return c;
 }
 
 void kr_destroy(kr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     resolve_stages(c);
+    for (int i = 0; i < c->nlanes; i++) {
+        Lane& ln = c->lanes[i];
+        DevBuf* lb[] = {&ln.codes, &ln.bad, &ln.partial8, &ln.base1, &ln.tmpkeys, &ln.tp, &ln.tiledesc, &ln.tilehist};
+        for (DevBuf* b : lb) release(c, *b);
+    }
     for (auto& kv : c->genomes) {
         release(c, kv.second.bases);
         release(c, kv.second.keys);
         release(c, kv.second.off);
         release(c, kv.second.chunkstart);
+        release(c, kv.second.chunkdesc);
         release(c, kv.second.ovf);
     }
-    DevBuf* all[] = {&c->codes, &c->bad, &c->partial8, &c->base1, &c->tp, &c->tiled1, &c->tilehist,
-                     &c->tmpkeys, &c->candA, &c->candB, &c->chunkcnt,
+    DevBuf* all[] = {&c->candA, &c->candB, &c->chunkcnt,
                      &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec};
     for (DevBuf* b : all) release(c, *b);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
-    (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < c->nlanes; i++) {
+        if (c->lanes[i].done) (void)hipEventDestroy(c->lanes[i].done);
+        if (c->lanes[i].stream) (void)hipStreamDestroy(c->lanes[i].stream);
+    }
     delete c;
 }
 
@@ -1193,19 +1280,21 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
     if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
     if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
     if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
+    if ((rc = ensure(c, G.chunkdesc, ((size_t)G.nchunks + 2) * 16))) return rc;
     if ((rc = ensure(c, G.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
-    // shared scratch sized for the largest genome
+    // per-lane scratch sized for the largest genome
     const u64 mw = (c->max_bases + 31) / 32 + 4;
-    if ((rc = ensure(c, c->codes, mw * 8))) return rc;
-    if ((rc = ensure(c, c->bad, mw * 4))) return rc;
-    if ((rc = ensure(c, c->partial8, (size_t)NWG * 256 * 4))) return rc;
-    if ((rc = ensure(c, c->base1, 260 * 4))) return rc;
-    if ((rc = ensure(c, c->tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
-    {
-        const u64 ntmax = 2 * (u64)c->max_bases / P2_TILE + 260;
-        if ((rc = ensure(c, c->tp, 260 * 4))) return rc;
-        if ((rc = ensure(c, c->tiled1, ntmax * 4))) return rc;
-        if ((rc = ensure(c, c->tilehist, ntmax * (nb >> 8) * 4))) return rc;
+    const u64 ntmax = 2 * (u64)c->max_bases / P2_TILE + 260;
+    for (int i = 0; i < c->nlanes; i++) {
+        Lane& ln = c->lanes[i];
+        if ((rc = ensure(c, ln.codes, mw * 8))) return rc;
+        if ((rc = ensure(c, ln.bad, mw * 4))) return rc;
+        if ((rc = ensure(c, ln.partial8, (size_t)NWG * 256 * 4))) return rc;
+        if ((rc = ensure(c, ln.base1, 260 * 4))) return rc;
+        if ((rc = ensure(c, ln.tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
+        if ((rc = ensure(c, ln.tp, 260 * 4))) return rc;
+        if ((rc = ensure(c, ln.tiledesc, ntmax * 8))) return rc;
+        if ((rc = ensure(c, ln.tilehist, ntmax * (nb >> 8) * 4))) return rc;
     }
     if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1221,59 +1310,65 @@ int kr_genome_sort(kr_ctx* c, int id) {
     Genome& G = it->second;
     const Geom g = c->g;
     const u32 nb = 1u << g.b;
-    hipStream_t st = c->stream;
-    u64* codes = (u64*)c->codes.p;
-    u32* bad = (u32*)c->bad.p;
+    Lane& ln = c->lanes[c->next_lane];
+    c->next_lane = (c->next_lane + 1) % c->nlanes;
+    ln.pending = true;
+    hipStream_t st = ln.stream;
+    u64* codes = (u64*)ln.codes.p;
+    u32* bad = (u32*)ln.bad.p;
     const u64 nwp = G.nwords + 2;   // two pad words (all bad) so window j may read word w+1
     G.sorted = G.finalized = false;
     G.count = -1;
     {
-        StageScope sc(c, KR_ST_PACK);
+        StageScope sc(c, KR_ST_PACK, st);
         u32 grid = (u32)std::min<u64>((nwp + 255) / 256, 4096);
         hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, st, (const uint8_t*)G.bases.p, (u64)G.n_bases, codes,
                            bad, nwp, g.omit);
     }
     {
-        StageScope sc(c, KR_ST_HIST);
+        StageScope sc(c, KR_ST_HIST, st);
         hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                           (u32*)c->partial8.p, g);
+                           (u32*)ln.partial8.p, g);
     }
     {
-        StageScope sc(c, KR_ST_SCAN);
-        hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)c->partial8.p, (u32*)c->base1.p,
-                           (u32*)c->tp.p, (u32*)c->tiled1.p);
+        StageScope sc(c, KR_ST_SCAN, st);
+        if (g.b > 8)
+            HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(G.nmax / P2_TILE) + 257) * 8, st));
+        hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p,
+                           (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
     }
-    u64* pass1_dst = g.b > 8 ? (u64*)c->tmpkeys.p : (u64*)G.keys.p;
+    u64* pass1_dst = g.b > 8 ? (u64*)ln.tmpkeys.p : (u64*)G.keys.p;
     {
-        StageScope sc(c, KR_ST_SCATTER1);
+        StageScope sc(c, KR_ST_SCATTER1, st);
         hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                           (const u32*)c->base1.p, (const u32*)c->partial8.p, pass1_dst, g);
+                           (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
     }
     {
-        StageScope sc(c, KR_ST_SCATTER2);
+        StageScope sc(c, KR_ST_SCATTER2, st);
         if (g.b > 8) {
             const u32 ntmax = (u32)(G.nmax / P2_TILE) + 257;
-            hipLaunchKernelGGL(k_hist2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)c->tmpkeys.p,
-                               (const u32*)c->base1.p, (const u32*)c->tp.p, (const u32*)c->tiled1.p,
-                               (u32*)c->tilehist.p, g.b);
-            hipLaunchKernelGGL(k_scan2, dim3(256), dim3(1024), 0, st, (u32*)c->tilehist.p, (const u32*)c->base1.p,
-                               (const u32*)c->tp.p, (u32*)G.off.p, g.b);
-            hipLaunchKernelGGL(k_scatter2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)c->tmpkeys.p,
-                               (u64*)G.keys.p, (const u32*)c->base1.p, (const u32*)c->tp.p,
-                               (const u32*)c->tiled1.p, (const u32*)c->tilehist.p, g.b);
+            hipLaunchKernelGGL(k_hist2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
+                               (const uint2*)ln.tiledesc.p, (u32*)ln.tilehist.p, g.b);
+            hipLaunchKernelGGL(k_scan2, dim3(256), dim3(1024), 0, st, (u32*)ln.tilehist.p, (const u32*)ln.base1.p,
+                               (const u32*)ln.tp.p, (u32*)G.off.p, g.b);
+            hipLaunchKernelGGL(k_scatter2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
+                               (u64*)G.keys.p, (const uint2*)ln.tiledesc.p, (const u32*)ln.tilehist.p, g.b);
         } else {
-            HIPCHK(c, hipMemcpyAsync(G.off.p, c->base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(G.off.p, ln.base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
         hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
                            (u32*)G.chunkstart.p);
+        hipLaunchKernelGGL(k_chunk_desc, dim3((G.nchunks + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p,
+                           (const u32*)G.chunkstart.p, G.nchunks, (uint4*)G.chunkdesc.p);
     }
     {
-        StageScope sc(c, KR_ST_LOCALSORT);
+        StageScope sc(c, KR_ST_LOCALSORT, st);
         HIPCHK(c, hipMemsetAsync(G.ovf.p, 0, 16, st));
-        hipLaunchKernelGGL(k_localsort, dim3(G.nchunks), dim3(LS_THREADS), 0, st, (u64*)G.keys.p,
-                           (const u32*)G.off.p, (const u32*)G.chunkstart.p, g.b, (u32*)G.ovf.p,
-                           (uint2*)((char*)G.ovf.p + 16));
+        const u32 grid = std::min<u32>(G.nchunks, (u32)c->ls_grid);
+        hipLaunchKernelGGL(k_localsort, dim3(grid), dim3(LS_THREADS), 0, st, (u64*)G.keys.p,
+                           (const u32*)G.off.p, (const uint4*)G.chunkdesc.p, G.nchunks, g.b, (u32*)G.ovf.p,
+                           (uint2*)((char*)G.ovf.p + 16), c->dbg);
     }
     G.sorted = true;      // enqueued; oversized buckets (if any) are resolved by finalize()
     return KR_OK;
@@ -1288,6 +1383,10 @@ static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
         if (G->sorted && !G->finalized) todo.push_back(G);
     if (todo.empty()) return KR_OK;
     hipStream_t st = c->stream;
+    {
+        int rcj = join_lanes(c);
+        if (rcj) return rcj;
+    }
     const u32 nb = 1u << c->g.b;
     std::vector<u32> novf(todo.size()), total(todo.size());
     for (size_t i = 0; i < todo.size(); i++) {
@@ -1342,6 +1441,7 @@ int64_t kr_genome_load_sorted(kr_ctx* c, int id, const uint64_t* keys, size_t n)
     if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
     if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
     if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
+    if ((rc = ensure(c, G.chunkdesc, ((size_t)G.nchunks + 2) * 16))) return rc;
     if ((rc = ensure(c, G.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
     hipStream_t st = c->stream;
     if (n) HIPCHK(c, hipMemcpyAsync(G.keys.p, keys, n * 8, hipMemcpyHostToDevice, st));
@@ -1350,6 +1450,8 @@ int64_t kr_genome_load_sorted(kr_ctx* c, int id, const uint64_t* keys, size_t n)
     HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
     hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
                        (u32*)G.chunkstart.p);
+    hipLaunchKernelGGL(k_chunk_desc, dim3((G.nchunks + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p,
+                       (const u32*)G.chunkstart.p, G.nchunks, (uint4*)G.chunkdesc.p);
     HIPCHK(c, hipMemsetAsync(G.ovf.p, 0, 16, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
@@ -1391,11 +1493,12 @@ int kr_genome_free(kr_ctx* c, int id) {
     if (!c) return KR_ERR_PARAM;
     auto it = c->genomes.find(id);
     if (it == c->genomes.end()) return fail(c, KR_ERR_PARAM, "unknown genome %d", id);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     release(c, it->second.bases);
     release(c, it->second.keys);
     release(c, it->second.off);
     release(c, it->second.chunkstart);
+    release(c, it->second.chunkdesc);
     release(c, it->second.ovf);
     c->genomes.erase(it);
     return KR_OK;
@@ -1410,10 +1513,7 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     a.n = n;
     a.ingroup_bits = 0;
     a.apply_filter = apply_filter ? 1 : 0;
-    {
-        const char* e = getenv("KR_DBG");
-        a.dbg = e ? atoi(e) : 0;
-    }
+    a.dbg = c->dbg;
     int anchor = 0;
     u64 best = ~0ull;
     std::vector<Genome*> gs;
@@ -1430,7 +1530,7 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     if ((rc0 = finalize(c, gs))) return rc0;
     Genome& A = *gs[anchor];
     a.anchor = anchor;
-    a.chunkstart = (const u32*)A.chunkstart.p;
+    a.chunkdesc = (const uint4*)A.chunkdesc.p;
     int rc;
     if ((rc = ensure(c, c->candA, (A.nmax + 2) * sizeof(kr_cand)))) return rc;
     if ((rc = ensure(c, c->candB, (A.nmax + 2) * sizeof(kr_cand)))) return rc;
@@ -1450,7 +1550,7 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
         StageScope sc(c, KR_ST_COMPACT);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->chunkcnt.p, (u32*)c->chunkpos.p, A.nchunks);
         hipLaunchKernelGGL(k_gather_cands, dim3(A.nchunks), dim3(64), 0, st, (const kr_cand*)c->candA.p,
-                           (const u32*)A.chunkstart.p, (const u32*)A.off.p, (const u32*)c->chunkcnt.p,
+                           (const uint4*)A.chunkdesc.p, (const u32*)c->chunkcnt.p,
                            (const u32*)c->chunkpos.p, (kr_cand*)c->candB.p);
     }
     u32 total = 0;
@@ -1574,6 +1674,10 @@ int64_t kr_fetch(kr_ctx* c, kr_record* out, size_t cap) {
 int kr_sync(kr_ctx* c) {
     if (!c) return KR_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        int rcj = join_lanes(c);
+        if (rcj) return rcj;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     return KR_OK;
@@ -1603,7 +1707,7 @@ int kr_stage_enable(kr_ctx* c, int on) {
 
 int kr_stage_reset(kr_ctx* c) {
     if (!c) return KR_ERR_PARAM;
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     resolve_stages(c);
     for (int i = 0; i < KR_ST_COUNT; i++) { c->stage_ms[i] = 0; c->stage_n[i] = 0; }
     return KR_OK;
@@ -1611,7 +1715,7 @@ int kr_stage_reset(kr_ctx* c) {
 
 double kr_stage_ms(kr_ctx* c, int stage) {
     if (!c || stage < 0 || stage >= KR_ST_COUNT) return -1.0;
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     resolve_stages(c);
     return c->stage_ms[stage];
 }
@@ -1627,18 +1731,19 @@ int64_t kr_debug_fetch(kr_ctx* c, int id, int what, void* out, size_t cap_bytes)
     if (it == c->genomes.end()) return fail(c, KR_ERR_PARAM, "unknown genome %d", id);
     Genome& G = it->second;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());
+    Lane& ln = c->lanes[(c->next_lane + c->nlanes - 1) % c->nlanes];   // the lane of the latest sort
     const u32 nb = 1u << c->g.b;
     const void* src = nullptr;
     size_t esz = 8, n = 0;
     u32 total = 0;
     HIPCHK(c, hipMemcpy(&total, (u32*)G.off.p + nb, 4, hipMemcpyDeviceToHost));
     switch (what) {
-    case 0: src = c->codes.p; esz = 8; n = G.nwords + 2; break;
-    case 1: src = c->bad.p; esz = 4; n = G.nwords + 2; break;
-    case 2: src = c->base1.p; esz = 4; n = 257; break;
+    case 0: src = ln.codes.p; esz = 8; n = G.nwords + 2; break;
+    case 1: src = ln.bad.p; esz = 4; n = G.nwords + 2; break;
+    case 2: src = ln.base1.p; esz = 4; n = 257; break;
     case 3: src = G.off.p; esz = 4; n = nb + 1; break;
-    case 4: src = c->g.b > 8 ? c->tmpkeys.p : G.keys.p; esz = 8; n = total; break;
+    case 4: src = c->g.b > 8 ? ln.tmpkeys.p : G.keys.p; esz = 8; n = total; break;
     case 5: src = G.keys.p; esz = 8; n = total; break;
     default: return fail(c, KR_ERR_PARAM, "kr_debug_fetch: unknown selector %d", what);
     }
