@@ -769,18 +769,43 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
     __shared__ u32 sstart[MAXG], send[MAXG];
     const u32 tid = threadIdx.x;
     const uint4 cd = a.chunkdesc[blockIdx.x];
-    const u32 sa = cd.x, ea = cd.y;
+    const u32 sa = cd.x, ea = cd.y, chi = cd.w;
     if (sa >= ea) {
         if (tid == 0) a.chunkcnt[blockIdx.x] = 0;
         return;
     }
     const u64* KA = a.keys[a.anchor];
+    const u32* offA = a.off[a.anchor];
     const u32 full = a.n >= 32 ? 0xFFFFFFFFu : ((1u << a.n) - 1);
     const int LR = g.L + g.R;
+    const bool prefix_in_bucket = 2 * LR >= g.b;      // a (left,right) group never spans fine buckets
+    const bool anchor_in = (a.ingroup_bits >> a.anchor) & 1;
     u32 nout = 0;
-    for (u32 sub = sa; sub < ea; sub += IS_SUB) {
-        const u32 cnt = min(IS_SUB, ea - sub);
-        // all anchor loads of the sub-tile in flight at once
+    u32 fcur = cd.z;                                   // first bucket of the current sub-tile
+    bool start_ok = true;                              // the sub-tile starts on a bucket boundary
+    for (u32 sub = sa; sub < ea;) {
+        // ---- sub-tile = whole buckets, at most IS_SUB anchor keys (key-count split only for
+        //      a single bucket larger than that)
+        u32 fend = chi, subend = ea;
+        bool aligned = true;
+        if (ea - sub > IS_SUB) {
+            u32 l = fcur, r = chi;                     // largest f with offA[f] <= sub + IS_SUB
+            while (l < r) {
+                u32 mid = (l + r + 1) >> 1;
+                if (offA[mid] <= sub + IS_SUB) l = mid; else r = mid - 1;
+            }
+            if (l > fcur && offA[l] > sub) {
+                fend = l;
+                subend = offA[l];
+            } else {
+                aligned = false;
+                fend = fcur;
+                subend = sub + IS_SUB;
+            }
+        }
+        const u32 cnt = subend - sub;
+        const bool fast = start_ok && aligned && prefix_in_bucket && !(a.dbg & 32);
+        // ---- every load we can issue now: anchor keys, and (fast) the stream ranges
         u64 ak[IS_APT], pk[IS_APT];
 #pragma unroll
         for (int q = 0; q < (int)IS_APT; q++) {
@@ -789,7 +814,13 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
             ak[q] = p < cnt ? KA[gi] : 0;
             pk[q] = (p < cnt && gi > 0) ? KA[gi - 1] : 0;
         }
-        // distinct prefixes of the sub-tile, in order
+        if (fast && tid < (u32)a.n) {
+            u32 s0 = a.off[tid][fcur], e0 = a.off[tid][fend];
+            if ((int)tid == a.anchor || (a.dbg & 4)) e0 = s0;      // the anchor's own keys are in registers
+            sstart[tid] = s0;
+            send[tid] = e0;
+        }
+        // ---- distinct prefixes, in order
         bool flag[IS_APT];
         u32 pos[IS_APT];
 #pragma unroll
@@ -799,108 +830,128 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
         }
         const u32 nheads = compact_flags(flag, pos, masks, mpref);
 #pragma unroll
-        for (int q = 0; q < (int)IS_APT; q++)
-            if (flag[q]) heads[pos[q]] = ak[q] & g.pmask;
-        __syncthreads();
-        if (nheads == 0) continue;
-        const u64 first = heads[0], last = heads[nheads - 1];
-        const u64 span = last - first;
-        const int sh = span < IS_NB ? 0 : (64 - __clzll((long long)span) - 12);
-        const u32 fl = (u32)(first >> g.rb);
-        const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
-        if (tid < (u32)a.n) {
-            sstart[tid] = a.off[tid][fl];
-            send[tid] = (a.dbg & 4) ? sstart[tid] : a.off[tid][fh];
-        }
-        // order-preserving sub-bins over [first, last]: binstart[sb] = #heads with bin < sb
-        for (u32 h = tid; h < nheads; h += IS_THREADS) {
-            present[h] = 0;
-            inm[h] = 0;
-            if (WIDE) outm[h] = 0;
-            u32 sb = (u32)((heads[h] - first) >> sh);
-            u32 prev = h ? (u32)((heads[h - 1] - first) >> sh) + 1 : 0;
-            for (u32 q = prev; q <= sb; q++) binstart[q] = (unsigned short)h;
-        }
-        {
-            u32 lastbin = (u32)(span >> sh);
-            for (u32 q = lastbin + 1 + tid; q <= IS_NB; q += IS_THREADS) binstart[q] = (unsigned short)nheads;
-        }
-        __syncthreads();
-        // every genome (anchor included) streams its keys of the bucket range past the heads;
-        // the first batch of genome g+1 is in flight while genome g is probed
-        u64 cur[IS_APT], nxt[IS_APT];
-        {
-            const u64* K = a.keys[0];
-            const u32 s0 = sstart[0], e0 = send[0];
-#pragma unroll
-            for (int q = 0; q < (int)IS_APT; q++) {
-                u32 i = s0 + q * IS_THREADS + tid;
-                cur[q] = i < e0 ? K[i] : 0;
+        for (int q = 0; q < (int)IS_APT; q++) {
+            if (flag[q]) {
+                heads[pos[q]] = ak[q] & g.pmask;
+                present[pos[q]] = fast ? (1u << a.anchor) : 0u;
+                inm[pos[q]] = 0;
+                if (WIDE) outm[pos[q]] = 0;
             }
         }
-        for (int gi = 0; gi < a.n; gi++) {
-            const u64* K = a.keys[gi];
-            const u32 s = sstart[gi], e = send[gi];
-            const bool ing = (a.ingroup_bits >> gi) & 1;
-            if (gi + 1 < a.n) {
-                const u64* K2 = a.keys[gi + 1];
-                const u32 s2 = sstart[gi + 1], e2 = send[gi + 1];
+        __syncthreads();
+        if (nheads > 0) {
+            const u64 first = heads[0], last = heads[nheads - 1];
+            const u64 span = last - first;
+            const int sh = span < IS_NB ? 0 : (64 - __clzll((long long)span) - 12);
+            if (!fast && tid < (u32)a.n) {
+                const u32 fl = (u32)(first >> g.rb);
+                const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
+                u32 s0 = a.off[tid][fl];
+                sstart[tid] = s0;
+                send[tid] = (a.dbg & 4) ? s0 : a.off[tid][fh];
+            }
+            // order-preserving sub-bins over [first, last]: binstart[sb] = #heads with bin < sb
+            for (u32 h = tid; h < nheads; h += IS_THREADS) {
+                u32 sb = (u32)((heads[h] - first) >> sh);
+                u32 prev = h ? (u32)((heads[h - 1] - first) >> sh) + 1 : 0;
+                for (u32 q = prev; q <= sb; q++) binstart[q] = (unsigned short)h;
+            }
+            {
+                u32 lastbin = (u32)(span >> sh);
+                for (u32 q = lastbin + 1 + tid; q <= IS_NB; q += IS_THREADS) binstart[q] = (unsigned short)nheads;
+            }
+            if (fast && g.D > 0) {
+                // the anchor's own diagnostic columns, straight from registers
 #pragma unroll
                 for (int q = 0; q < (int)IS_APT; q++) {
-                    u32 i = s2 + q * IS_THREADS + tid;
-                    nxt[q] = i < e2 ? K2[i] : 0;
+                    u32 p = q * IS_THREADS + tid;
+                    if (p < cnt) {
+                        u32 h = flag[q] ? pos[q] : pos[q] - 1;
+                        u64 dm = diag_mask(ak[q], LR, g.D);
+                        if (WIDE) atomicOr((u64*)(anchor_in ? &inm[h] : &outm[h]), dm);
+                        else atomicOr((u64*)&inm[h], anchor_in ? dm : (dm << 32));
+                    }
                 }
             }
-            for (u32 i0 = s; i0 < e; i0 += IS_SUB) {
-                if (i0 != s) {
+            __syncthreads();
+            // ---- stream the genomes past the heads; first batch of genome g+1 in flight while g is probed
+            u64 cur[IS_APT], nxt[IS_APT];
+            {
+                const u64* K = a.keys[0];
+                const u32 s0 = sstart[0], e0 = send[0];
+#pragma unroll
+                for (int q = 0; q < (int)IS_APT; q++) {
+                    u32 i = s0 + q * IS_THREADS + tid;
+                    cur[q] = i < e0 ? K[i] : 0;
+                }
+            }
+            for (int gi = 0; gi < a.n; gi++) {
+                const u64* K = a.keys[gi];
+                const u32 s = sstart[gi], e = send[gi];
+                const bool ing = (a.ingroup_bits >> gi) & 1;
+                if (gi + 1 < a.n) {
+                    const u64* K2 = a.keys[gi + 1];
+                    const u32 s2 = sstart[gi + 1], e2 = send[gi + 1];
+#pragma unroll
+                    for (int q = 0; q < (int)IS_APT; q++) {
+                        u32 i = s2 + q * IS_THREADS + tid;
+                        nxt[q] = i < e2 ? K2[i] : 0;
+                    }
+                }
+                for (u32 i0 = s; i0 < e; i0 += IS_SUB) {
+                    if (i0 != s) {
+#pragma unroll
+                        for (int q = 0; q < (int)IS_APT; q++) {
+                            u32 i = i0 + q * IS_THREADS + tid;
+                            cur[q] = i < e ? K[i] : 0;
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < (int)IS_APT; q++) {
                         u32 i = i0 + q * IS_THREADS + tid;
-                        cur[q] = i < e ? K[i] : 0;
+                        if (i < e) {
+                            if (a.dbg & 1) asm volatile("" ::"v"(cur[q]));
+                            else
+                                isect_probe<WIDE>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm,
+                                                  outm, g, LR, a.dbg);
+                        }
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < (int)IS_APT; q++) {
-                    u32 i = i0 + q * IS_THREADS + tid;
-                    if (i < e) {
-                        if (a.dbg & 1) asm volatile("" ::"v"(cur[q]));
-                        else
-                            isect_probe<WIDE>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm,
-                                              outm, g, LR, a.dbg);
-                    }
+                for (int q = 0; q < (int)IS_APT; q++) cur[q] = nxt[q];
+            }
+            __syncthreads();
+            // ---- survivors, in order
+            u64 im[IS_APT], om[IS_APT];
+#pragma unroll
+            for (int q = 0; q < (int)IS_APT; q++) {
+                u32 h = q * IS_THREADS + tid;
+                flag[q] = false;
+                im[q] = om[q] = 0;
+                if (h < nheads) {
+                    flag[q] = present[h] == full;
+                    im[q] = WIDE ? inm[h] : (inm[h] & 0xFFFFFFFFull);
+                    om[q] = WIDE ? outm[h] : (inm[h] >> 32);
+                    if (flag[q] && a.apply_filter && g.D > 0) flag[q] = passes_filter(im[q], om[q], g.D);
                 }
             }
+            const u32 nsurv = compact_flags(flag, pos, masks, mpref);
 #pragma unroll
-            for (int q = 0; q < (int)IS_APT; q++) cur[q] = nxt[q];
-        }
-        __syncthreads();
-        // survivors, in order
-        u64 im[IS_APT], om[IS_APT];
-#pragma unroll
-        for (int q = 0; q < (int)IS_APT; q++) {
-            u32 h = q * IS_THREADS + tid;
-            flag[q] = false;
-            im[q] = om[q] = 0;
-            if (h < nheads) {
-                flag[q] = present[h] == full;
-                im[q] = WIDE ? inm[h] : (inm[h] & 0xFFFFFFFFull);
-                om[q] = WIDE ? outm[h] : (inm[h] >> 32);
-                if (flag[q] && a.apply_filter && g.D > 0) flag[q] = passes_filter(im[q], om[q], g.D);
+            for (int q = 0; q < (int)IS_APT; q++) {
+                if (flag[q]) {
+                    kr_cand c;
+                    c.prefix = heads[q * IS_THREADS + tid];
+                    c.in_mask = im[q];
+                    c.out_mask = om[q];
+                    a.tmp[(u64)sa + nout + pos[q]] = c;
+                }
             }
+            nout += nsurv;
+            __syncthreads();
         }
-        const u32 nsurv = compact_flags(flag, pos, masks, mpref);
-#pragma unroll
-        for (int q = 0; q < (int)IS_APT; q++) {
-            if (flag[q]) {
-                kr_cand c;
-                c.prefix = heads[q * IS_THREADS + tid];
-                c.in_mask = im[q];
-                c.out_mask = om[q];
-                a.tmp[(u64)sa + nout + pos[q]] = c;
-            }
-        }
-        nout += nsurv;
-        __syncthreads();
+        sub = subend;
+        fcur = fend;
+        start_ok = aligned;
     }
     if (tid == 0) a.chunkcnt[blockIdx.x] = nout;
 }
