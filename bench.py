@@ -34,8 +34,9 @@ MODEL_BYTES_PER_KMER = 136.5    # 0.5 + W + W + 2*W*P + W at W =
 # the stage's share of SURVEY 8(d)'s model -- bases in, key write, pass read+write, intersect read.
 STAGE_BYTES = {
     "pack": 0.5 + 0.1875,           # 1 B/base in, 3 bits/base out; two records per base
-    "hist": 0.1875,                 # codes + bad bits in (per sweep)
+    "hist8": 0.1875,                # codes + bad bits in
     "scatter1": 0.1875 + 8.0,       # codes in, one 8-byte key out
+    "hist2": 8.0,                   # key in
     "scatter2": 16.0,               # key in, key out
     "localsort": 16.0,              # key in, key out
     "intersect": 8.0,               # every key of every genome read once
@@ -44,23 +45,32 @@ STAGE_BYTES = {
 
 def make_genomes(config, rank, world, per_rank, length, independent=False):
     from krisp_amd import synth
-    total = per_rank * world
-    n_in = total // 2
     anc = None if independent else synth.ancestor(config, length)
     out = []
     for g in range(rank * per_rank, (rank + 1) * per_rank):
-        ing = g < n_in
+        # every rank holds half ingroup / half outgroup genomes of the 4N-genome family, so the
+        # diagnostic filter can already prune locally (it is monotone: DESIGN.md "Multi-GPU")
+        ing = (g % per_rank) < per_rank // 2
         codes = synth.genome_codes(config, g, length, ing, mu=0.01, snp_every=10000,
                                    independent=independent, anc=anc)
         out.append((g, ing, synth.codes_to_text(codes, records=16)))
     return out
 
 
-def cpu_baseline(config, L, D, R, length):
-    """The packed-key C oracle (oracle/kmer_oracle.c, 1 thread) on a bounded sample
-    of the same workload: same generator and parameters, shorter genomes."""
+def cpu_baseline(config, L, D, R, length, full_length):
+    """The packed-key C oracle (oracle/kmer_oracle.c, 1 thread) on a bounded sample of the
+    same workload: same generator and parameters, genomes shortened so that the run takes
+    roughly 10-20 s on this host (calibrated on 4 x 1 Mbp first)."""
     from oracle import kmer_oracle as K
     K.build()
+    if length <= 0:
+        cal = make_genomes(config, 0, 1, 4, 1_000_000)
+        t0 = time.perf_counter()
+        ck = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in cal]
+        K.intersect(ck, [f for _, f, _ in cal], L, D, R, apply_filter=True)
+        per_mbp = (time.perf_counter() - t0) / 4.0
+        length = int(min(full_length, max(1_000_000, 15.0 / (4.0 * per_mbp) * 1e6)))
+        length -= length % 1_000_000
     fam = make_genomes(config, 0, 1, 4, length)
     t0 = time.perf_counter()
     keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
@@ -82,9 +92,12 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=4, help="genomes per GPU")
     ap.add_argument("--ldr", type=int, nargs=3, default=[25, 1, 2])
     ap.add_argument("--independent", action="store_true", help="independent random genomes")
-    ap.add_argument("--cpu-length", type=int, default=5_000_000)
+    ap.add_argument("--cpu-length", type=int, default=0,
+                    help="bases per genome of the CPU baseline sample (0 = calibrate to ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) even at world size 1 (plumbing self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +112,7 @@ def main():
     from krisp_amd import _native
     dist = None
     device = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -130,7 +143,7 @@ def main():
             eng.sort(g)
         if world == 1:
             return eng.intersect(ids, flags, apply_filter=True)
-        eng.intersect(ids, flags, apply_filter=False)
+        eng.intersect(ids, flags, apply_filter=True)     # safe local pruning (monotone predicate)
         return tree_reduce_candidates(eng, dist, rank, world, apply_filter=True, device=device)
 
     for _ in range(args.warmup):
@@ -171,14 +184,18 @@ def main():
             # hist launches once per sweep, intersect once per step over all local genomes
             per_launch = kmers_local if dom == "intersect" else kmers_local / len(ids)
             achieved = STAGE_BYTES[dom] * per_launch / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch of the same kernel from the PMC counters (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE passes of this command, profiles/make_traffic.py), valid for
+            # the default workload only; expressed like `achieved`: bytes per launch / launch time
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile):
+            if os.path.exists(tfile) and args.length == 50_000_000 and args.per_gpu == 4 and [L, D, R] == [25, 1, 2]:
                 try:
-                    traffic = json.load(open(tfile)).get(dom)
+                    tb = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
+                    traffic = round(tb / (avg_ms * 1e-3) / 1e9, 1) if tb else None
                 except Exception:  # noqa: BLE001
                     traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "bytes_per_kmer": STAGE_BYTES[dom], "kmers_per_launch": per_launch,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
@@ -198,7 +215,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(config, L, D, R, args.cpu_length)
+            out["cpu_baseline"] = cpu_baseline(config, L, D, R, args.cpu_length, args.length)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -16,8 +16,14 @@ CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 
 SOFT_MAP, SOFT_OMIT = 0, 1
-STAGES = ["pack", "hist", "scan", "scatter1", "scatter2", "localsort", "fallback",
-          "intersect", "compact", "collect", "merge"]
+STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
+          "fallback", "intersect", "compact", "collect", "merge"]
+# stage -> the kernel(s) it times (names as rocprofv3 prints them)
+STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1",
+                 "hist2": "k_hist2", "scan2": "k_scan2", "scatter2": "k_scatter2",
+                 "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort",
+                 "fallback": "k_bitonic_stage", "intersect": "k_intersect", "compact": "k_scan+k_gather_cands",
+                 "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact"}
 
 # every symbol include/krisp_hip.h declares: (name, restype, argtypes)
 _c = ctypes

@@ -129,28 +129,53 @@ __global__ void k_pack(const uint8_t* __restrict__ bases, u64 n, u64* __restrict
 // K2  per-workgroup histogram of the top key byte, straight from the codes.
 // (The finer digit of pass 2 is counted by the pass-2 workgroup itself.)
 // ----------------------------------------------------------------------------
+// top key byte of both strands of window j without building the keys (valid when L >= 4:
+// the first four bases of `left` are the first four bases of the strand's window)
+__device__ __forceinline__ bool window_top_bytes(u64 c0, u64 c1, u32 b0, u32 b1, int j, int k, u32& tf, u32& tr) {
+    u64 x = j ? ((c0 << (2 * j)) | (c1 >> (64 - 2 * j))) : c0;
+    u32 bm = j ? ((b0 << j) | (b1 >> (32 - j))) : b0;
+    if ((bm >> (32 - k)) != 0) return false;
+    tf = (u32)(x >> 56);
+    u32 t = (u32)(x >> (64 - 2 * k)) & 0xFFu;      // last four bases of the window
+    t = ~t & 0xFFu;                                 // complement
+    t = ((t & 0x03u) << 6) | ((t & 0x0Cu) << 2) | ((t & 0x30u) >> 2) | ((t & 0xC0u) >> 6);   // reverse
+    tr = t;
+    return true;
+}
+
 __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                u64 nwords, u32* __restrict__ partial8, Geom g) {
     __shared__ u32 lhist[256];
-    lhist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) lhist[threadIdx.x] = 0;
     __syncthreads();
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
+    const bool cheap = g.L >= 4;
     for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
         u64 c0 = codes[w], c1 = codes[w + 1];
+        if (cheap) {
+#pragma unroll 8
+            for (int j = 0; j < 32; j++) {
+                u32 tf, tr;
+                if (!window_top_bytes(c0, c1, b0, b1, j, g.k, tf, tr)) continue;
+                atomicAdd(&lhist[tf], 1u);
+                atomicAdd(&lhist[tr], 1u);
+            }
+        } else {
 #pragma unroll 4
-        for (int j = 0; j < 32; j++) {
-            u64 kf, kr;
-            if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
-            atomicAdd(&lhist[(u32)(kf >> 56)], 1u);
-            atomicAdd(&lhist[(u32)(kr >> 56)], 1u);
+            for (int j = 0; j < 32; j++) {
+                u64 kf, kr;
+                if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
+                atomicAdd(&lhist[(u32)(kf >> 56)], 1u);
+                atomicAdd(&lhist[(u32)(kr >> 56)], 1u);
+            }
         }
     }
     __syncthreads();
-    partial8[(u64)blockIdx.x * 256 + threadIdx.x] = lhist[threadIdx.x];
+    if (threadIdx.x < 256) partial8[(u64)blockIdx.x * 256 + threadIdx.x] = lhist[threadIdx.x];
 }
 
 // ----------------------------------------------------------------------------
@@ -1081,7 +1106,7 @@ struct kr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;     // main stream = lanes[0].stream
     Lane lanes[MAX_LANES];
-    int nlanes = 2, next_lane = 0;
+    int nlanes = 1, next_lane = 0;
     size_t budget = 0, used = 0;
     bool have_params = false;
     Geom g{};
@@ -1232,7 +1257,7 @@ kr_ctx* kr_create(int device, size_t hbm_budget_bytes) {
     }
     {
         const char* e = getenv("KR_LANES");
-        int nl = e ? atoi(e) : 2;
+        int nl = e ? atoi(e) : 1;   // > 1 overlaps consecutive genome sorts (+0-7 %, box dependent)
         c->nlanes = nl < 1 ? 1 : (nl > MAX_LANES ? MAX_LANES : nl);
     }
     bool ok = hipEventCreate(&c->t0) == hipSuccess && hipEventCreate(&c->t1) == hipSuccess;
@@ -1377,12 +1402,12 @@ int kr_genome_sort(kr_ctx* c, int id) {
                            bad, nwp, g.omit);
     }
     {
-        StageScope sc(c, KR_ST_HIST, st);
+        StageScope sc(c, KR_ST_HIST8, st);
         hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
                            (u32*)ln.partial8.p, g);
     }
     {
-        StageScope sc(c, KR_ST_SCAN, st);
+        StageScope sc(c, KR_ST_REDUCE8, st);
         if (g.b > 8)
             HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(G.nmax / P2_TILE) + 257) * 8, st));
         hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p,
@@ -1394,19 +1419,28 @@ int kr_genome_sort(kr_ctx* c, int id) {
         hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
                            (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
     }
-    {
-        StageScope sc(c, KR_ST_SCATTER2, st);
-        if (g.b > 8) {
-            const u32 ntmax = (u32)(G.nmax / P2_TILE) + 257;
+    if (g.b > 8) {
+        const u32 ntmax = (u32)(G.nmax / P2_TILE) + 257;
+        {
+            StageScope sc(c, KR_ST_HIST2, st);
             hipLaunchKernelGGL(k_hist2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
                                (const uint2*)ln.tiledesc.p, (u32*)ln.tilehist.p, g.b);
+        }
+        {
+            StageScope sc(c, KR_ST_SCAN2, st);
             hipLaunchKernelGGL(k_scan2, dim3(256), dim3(1024), 0, st, (u32*)ln.tilehist.p, (const u32*)ln.base1.p,
                                (const u32*)ln.tp.p, (u32*)G.off.p, g.b);
+        }
+        {
+            StageScope sc(c, KR_ST_SCATTER2, st);
             hipLaunchKernelGGL(k_scatter2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
                                (u64*)G.keys.p, (const uint2*)ln.tiledesc.p, (const u32*)ln.tilehist.p, g.b);
-        } else {
-            HIPCHK(c, hipMemcpyAsync(G.off.p, ln.base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
         }
+    } else {
+        HIPCHK(c, hipMemcpyAsync(G.off.p, ln.base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
+    }
+    {
+        StageScope sc(c, KR_ST_CHUNKS, st);
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
         hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
                            (u32*)G.chunkstart.p);

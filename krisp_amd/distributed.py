@@ -51,9 +51,12 @@ def _recv(dist, src, device, dtype):
 
 
 def tree_reduce_candidates(engine, dist, rank, world, apply_filter, device=None):
-    """Every rank holds the UNFILTERED candidates of its own genomes in `engine`.
-    After the call rank 0 holds the candidates present on every rank, masks OR-ed
-    (and filtered when apply_filter); other ranks' candidate sets are spent.
+    """Every rank holds the candidates of its own genomes in `engine` (unfiltered, or
+    already pruned with the diagnostic filter: the predicate "some column has disjoint
+    ingroup / outgroup base sets" is monotone -- masks only grow under merging -- so a
+    candidate that fails it on partial masks fails it globally and may be dropped at
+    any stage).  After the call rank 0 holds the candidates present on every rank, masks
+    OR-ed (and filtered when apply_filter); other ranks' candidate sets are spent.
     Returns the final count on rank 0, -1 elsewhere.  log2(world) rounds."""
     step = 1
     active = True
@@ -63,7 +66,7 @@ def tree_reduce_candidates(engine, dist, rank, world, apply_filter, device=None)
                 partner = rank + step
                 if partner < world:
                     other = _recv(dist, partner, device, CAND)
-                    engine.merge_cands(other, apply_filter=False)
+                    engine.merge_cands(other, apply_filter=apply_filter)
             else:
                 _send(dist, engine.cands(), rank - step, device)
                 active = False

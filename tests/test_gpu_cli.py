@@ -168,3 +168,66 @@ def test_readme_known_answers_on_the_gpu(tmp_path):
         "                        {#}\n\n")
     single = _run_main([ing[0], "--conserved", "14", "--diagnostic", "0"])
     assert single.startswith("left_seq,diag_seq,right_seq\n") and single.count("\n") > 1000
+
+
+DIST_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["KR_ROOT"])
+import torch.distributed as dist
+from krisp_amd import _native, distributed as D, synth
+from oracle import kmer_oracle as K
+
+L, Dg, R = 25, 1, 2
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+fam = synth.family(6, 3, 3, 150_000, records=3, mu=0.01, snp_every=1500)
+mine = D.shard(list(range(len(fam))), rank, world)
+eng = _native.Engine(device=0)
+eng.set_params(L, Dg, R, max_bases=max(len(t) for _, _, t in fam))
+for g in mine:
+    eng.upload(g, fam[g][2])
+    eng.sort(g)
+eng.intersect(mine, [fam[g][1] for g in mine], apply_filter=False)
+n = D.tree_reduce_candidates(eng, dist, rank, world, apply_filter=True)
+D.broadcast_candidates(eng, dist, rank, world)
+recs = eng.collect(mine)
+allrec = D.gather_records(recs, dist, rank, world)
+if rank == 0:
+    keys = [K.sorted_keys(t.tobytes(), L, Dg, R) for _, _, t in fam]
+    want = K.intersect(keys, [f for _, f, _ in fam], L, Dg, R, apply_filter=True)
+    got = eng.cands()
+    assert n == len(want) > 0, (n, len(want))
+    assert np.array_equal(got["prefix"], want["prefix"]) and np.array_equal(got["in_mask"], want["in_mask"])
+    assert np.array_equal(got["out_mask"], want["out_mask"])
+    a = np.sort(allrec, order=["key", "genome"])
+    b = np.sort(K.collect(keys, want, L, Dg, R), order=["key", "genome"])
+    assert np.array_equal(a, b)
+    print("GPU_DIST_OK", n, len(allrec))
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
+    """The real engine in the N > 1 flow (sharding, device list merges, broadcast, gather);
+    two processes on cuda:0, gloo transport (RCCL needs one GPU per rank)."""
+    import socket
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(DIST_WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KR_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "GPU_DIST_OK" in outs[0], outs[0]
