@@ -208,35 +208,59 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* lds_waves /* >= 17 u3
 // in place exclusive prefix over the workgroups (= that workgroup's private pass-1
 // cursor offset inside bucket d), then a scan over d gives the bucket bases.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce8(u32* __restrict__ partial8, u32* __restrict__ base1,
-                                                 u32* __restrict__ tp, uint2* __restrict__ tiledesc) {
+// (a) one workgroup per top-byte column d: exclusive prefix over the NWG persistent
+//     workgroups, in place (= each workgroup's private pass-1 cursor offset), column total out
+__global__ __launch_bounds__(256) void k_reduce8a(u32* __restrict__ partial8, u32* __restrict__ tot) {
     __shared__ u32 waves[17];
-    const u32 d = threadIdx.x;
-    u32 run = 0;
-    for (u32 wg = 0; wg < NWG; wg += 8) {
-        u32 v[8];
+    const u32 d = blockIdx.x;
+    const u32 PER = NWG / 256;
+    u32 v[PER];
+    u32 sum = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = partial8[(u64)(wg + q) * 256 + d];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            partial8[(u64)(wg + q) * 256 + d] = run;
-            run += v[q];
-        }
+    for (u32 q = 0; q < PER; q++) {
+        v[q] = partial8[(u64)(threadIdx.x * PER + q) * 256 + d];
+        sum += v[q];
     }
     u32 total;
-    u32 ex = block_excl_scan(run, waves, total);
-    base1[d] = ex;
-    if (d == 0) base1[256] = total;
-    // pass-2 tiles never straddle a bucket: tp[d] = first tile of bucket d,
-    // tiledesc[tile] = its key range (pre-zeroed: unused tiles are empty)
-    const u32 ntile = (run + P2_TILE - 1) / P2_TILE;
+    u32 ex = block_excl_scan(sum, waves, total);
+#pragma unroll
+    for (u32 q = 0; q < PER; q++) {
+        partial8[(u64)(threadIdx.x * PER + q) * 256 + d] = ex;
+        ex += v[q];
+    }
+    if (threadIdx.x == 0) tot[d] = total;
+}
+
+// (b) bucket bases and the pass-2 tile table (tiles never straddle a bucket: tp[d] = first
+//     tile of bucket d, tiledesc[tile] = its key range; pre-zeroed, unused tiles are empty)
+__global__ __launch_bounds__(1024) void k_reduce8b(const u32* __restrict__ tot, u32* __restrict__ base1,
+                                                   u32* __restrict__ tp, uint2* __restrict__ tiledesc) {
+    __shared__ u32 waves[17];
+    __shared__ u32 sb[3][256];
+    const u32 d = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const u32 colsum = part == 0 ? tot[d] : 0;
+    u32 total;
+    u32 ex = block_excl_scan(colsum, waves, total);
+    const u32 ntile = part == 0 ? (colsum + P2_TILE - 1) / P2_TILE : 0;
     u32 ttotal;
     u32 t0 = block_excl_scan(ntile, waves, ttotal);
-    tp[d] = t0;
-    if (d == 0) tp[256] = ttotal;
-    for (u32 t = 0; t < ntile; t++) {
-        u32 ts = ex + t * P2_TILE;
-        tiledesc[t0 + t] = make_uint2(ts, min(ex + run, ts + P2_TILE));
+    if (part == 0) {
+        base1[d] = ex;
+        if (d == 0) base1[256] = total;
+        tp[d] = t0;
+        if (d == 0) tp[256] = ttotal;
+        sb[0][d] = ex;
+        sb[1][d] = colsum;
+        sb[2][d] = t0;
+    }
+    __syncthreads();
+    for (u32 dd = part; dd < 256; dd += 4) {
+        const u32 bex = sb[0][dd], brun = sb[1][dd], bt0 = sb[2][dd];
+        const u32 nt = (brun + P2_TILE - 1) / P2_TILE;
+        for (u32 t = d; t < nt; t += 256) {
+            u32 ts = bex + t * P2_TILE;
+            tiledesc[bt0 + t] = make_uint2(ts, min(bex + brun, ts + P2_TILE));
+        }
     }
 }
 
@@ -382,14 +406,34 @@ __global__ __launch_bounds__(1024) void k_scan2(u32* __restrict__ tilehist, cons
     const u32 d1 = blockIdx.x, bin = threadIdx.x;
     const u32 t0 = tp[d1], t1 = tp[d1 + 1];
     u32 tot = 0;
-    if (bin < nb2)
-        for (u32 t = t0; t < t1; t++) tot += tilehist[(u64)t * nb2 + bin];
+    if (bin < nb2) {
+        u32 t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = tilehist[(u64)(t + q) * nb2 + bin];
+#pragma unroll
+            for (int q = 0; q < 8; q++) tot += v[q];
+        }
+        for (; t < t1; t++) tot += tilehist[(u64)t * nb2 + bin];
+    }
     u32 total;
     u32 ex = block_excl_scan(tot, waves, total);
     u32 run = base1[d1] + ex;
     if (bin < nb2) {
         off[d1 * nb2 + bin] = run;
-        for (u32 t = t0; t < t1; t++) {
+        u32 t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = tilehist[(u64)(t + q) * nb2 + bin];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                tilehist[(u64)(t + q) * nb2 + bin] = run;
+                run += v[q];
+            }
+        }
+        for (; t < t1; t++) {
             u32 v = tilehist[(u64)t * nb2 + bin];
             tilehist[(u64)t * nb2 + bin] = run;
             run += v;
@@ -1366,7 +1410,7 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
         if ((rc = ensure(c, ln.codes, mw * 8))) return rc;
         if ((rc = ensure(c, ln.bad, mw * 4))) return rc;
         if ((rc = ensure(c, ln.partial8, (size_t)NWG * 256 * 4))) return rc;
-        if ((rc = ensure(c, ln.base1, 260 * 4))) return rc;
+        if ((rc = ensure(c, ln.base1, (260 + 256) * 4))) return rc;     // bases[257] | column totals[256]
         if ((rc = ensure(c, ln.tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
         if ((rc = ensure(c, ln.tp, 260 * 4))) return rc;
         if ((rc = ensure(c, ln.tiledesc, ntmax * 8))) return rc;
@@ -1410,8 +1454,9 @@ int kr_genome_sort(kr_ctx* c, int id) {
         StageScope sc(c, KR_ST_REDUCE8, st);
         if (g.b > 8)
             HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(G.nmax / P2_TILE) + 257) * 8, st));
-        hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p,
-                           (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
+        hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+        hipLaunchKernelGGL(k_reduce8b, dim3(1), dim3(1024), 0, st, (const u32*)ln.base1.p + 260,
+                           (u32*)ln.base1.p, (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
     }
     u64* pass1_dst = g.b > 8 ? (u64*)ln.tmpkeys.p : (u64*)G.keys.p;
     {
