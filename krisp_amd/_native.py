@@ -219,7 +219,7 @@ class Engine:
         o = np.zeros(8, dtype=np.int64)
         self.lib.kr_debug_info(self.ctx, _ptr(o))
         return dict(b=int(o[0]), nbuckets=int(o[1]), T=int(o[2]), CAP=int(o[3]), nwg=int(o[4]),
-                    overflow_segments=int(o[5]), fallback_launches=int(o[6]), hbm_bytes=int(o[7]))
+                    overflow_segments=int(o[5]), fallback_launches=int(o[6]), nslices=int(o[7]))
 
     def debug_fetch(self, gid, what, n_max):
         dt = {0: np.uint64, 1: np.uint32, 2: np.uint32, 3: np.uint32, 4: np.uint64, 5: np.uint64}[what]

@@ -25,15 +25,31 @@ typedef unsigned int u32;
 // geometry shared by every kernel
 // ----------------------------------------------------------------------------
 struct Geom {
+    // --- absolute key geometry (key generation)
     int k, L, D, R;
-    int b;          // radix fan-out bits of the two MSD passes (8 .. 18)
-    int rb;         // 64 - b
     int sR, sD;     // layout shifts: right part << sR (= 2D), diag part >> sD (= 2R)
     u64 topmask;    // top 2k bits
     u64 mL, mR, mD; // destination masks of left / right / diag in [left|right|diag]
-    u64 pmask;      // top 2(L+R) bits: the (left,right) prefix
     int omit;       // soft-mask rule
+    // --- key-space slice: genomes too large for one sort unit are sorted in 4^sb slices, one
+    // per value of the first sb bases of `left`; inside a slice keys are stored RELATIVE
+    // (absolute key << sbits): the slice is the same problem with geometry (L - sb, D, R)
+    int sbits;      // 2 * sb
+    u32 slice;      // value of the top sbits of the keys of this slice
+    // --- relative geometry (everything after key generation)
+    int b;          // radix fan-out bits of the two MSD passes (8 .. 18)
+    int rb;         // 64 - b
+    int LRrel;      // L - sb + R: bases of the (left,right) prefix of a relative key
+    u64 pmask;      // top 2 * LRrel bits of a relative key
 };
+
+// absolute key -> relative key of the current slice; false when the key is not in the slice
+__device__ __forceinline__ bool slice_key(u64& key, const Geom& g) {
+    if (g.sbits == 0) return true;
+    if ((u32)(key >> (64 - g.sbits)) != g.slice) return false;
+    key <<= g.sbits;
+    return true;
+}
 
 #define NWG 1024           // persistent workgroups of the histogram / pass-1 kernels (4 per CU)
 #define P1_T 256           // threads of those workgroups
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
-    const bool cheap = g.L >= 4;
+    const bool cheap = g.L >= 4 && g.sbits == 0;
     for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
@@ -169,8 +185,8 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
             for (int j = 0; j < 32; j++) {
                 u64 kf, kr;
                 if (!window_keys(c0, c1, b0, b1, j, g, kf, kr)) continue;
-                atomicAdd(&lhist[(u32)(kf >> 56)], 1u);
-                atomicAdd(&lhist[(u32)(kr >> 56)], 1u);
+                if (slice_key(kf, g)) atomicAdd(&lhist[(u32)(kf >> 56)], 1u);
+                if (slice_key(kr, g)) atomicAdd(&lhist[(u32)(kr >> 56)], 1u);
             }
         }
     }
@@ -335,9 +351,8 @@ __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes
                 for (int jj = 0; jj < 8; jj++) {
                     u64 kf, kr;
                     if (window_keys(c0, c1, b0, b1, j0 + jj, g, kf, kr)) {
-                        key[2 * jj] = kf;
-                        key[2 * jj + 1] = kr;
-                        vm |= 3u << (2 * jj);
+                        if (slice_key(kf, g)) { key[2 * jj] = kf; vm |= 1u << (2 * jj); }
+                        if (slice_key(kr, g)) { key[2 * jj + 1] = kr; vm |= 2u << (2 * jj); }
                     }
                 }
             }
@@ -846,7 +861,7 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
     const u64* KA = a.keys[a.anchor];
     const u32* offA = a.off[a.anchor];
     const u32 full = a.n >= 32 ? 0xFFFFFFFFu : ((1u << a.n) - 1);
-    const int LR = g.L + g.R;
+    const int LR = g.LRrel;
     const bool prefix_in_bucket = 2 * LR >= g.b;      // a (left,right) group never spans fine buckets
     const bool anchor_in = (a.ingroup_bits >> a.anchor) & 1;
     u32 nout = 0;
@@ -1027,14 +1042,19 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
 
 // ----------------------------------------------------------------------------
 // K6b  dense, ordered candidate list from the per-chunk runs
-__global__ void k_gather_cands(const kr_cand* __restrict__ tmp, const uint4* __restrict__ chunkdesc,
-                               const u32* __restrict__ chunkcnt,
+__global__ void k_gather_cands(int sbits, u32 slice, const kr_cand* __restrict__ tmp,
+                               const uint4* __restrict__ chunkdesc, const u32* __restrict__ chunkcnt,
                                const u32* __restrict__ chunkpos, kr_cand* __restrict__ out) {
     u32 n = chunkcnt[blockIdx.x];
     if (n == 0) return;
     u64 src = chunkdesc[blockIdx.x].x;
     u32 dst = chunkpos[blockIdx.x];
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[dst + i] = tmp[src + i];
+    const u64 top = sbits ? ((u64)slice << (64 - sbits)) : 0;
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        kr_cand c = tmp[src + i];
+        c.prefix = top | (c.prefix >> sbits);          // relative -> absolute prefix
+        out[dst + i] = c;
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -1045,7 +1065,9 @@ __global__ void k_collect(const kr_cand* __restrict__ cands, u32 ncand, const u6
                           u64 cap, u64* __restrict__ nrec) {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncand) return;
-    u64 pre = cands[c].prefix;
+    u64 pre = cands[c].prefix;                          // absolute
+    if (!slice_key(pre, g)) return;                     // -> relative, or not in this slice
+    const u64 top = g.sbits ? ((u64)g.slice << (64 - g.sbits)) : 0;
     u32 f = (u32)(pre >> g.rb);
     u32 f2 = (u32)((pre | ~g.pmask) >> g.rb) + 1;
     u32 l = off[f], r = off[f2];
@@ -1062,7 +1084,7 @@ __global__ void k_collect(const kr_cand* __restrict__ cands, u32 ncand, const u6
         u64 idx = atomicAdd(nrec, 1ull);
         if (out && idx < cap) {
             kr_record rec;
-            rec.key = key;
+            rec.key = top | (key >> g.sbits);
             rec.genome = genome_id;
             rec.count = cnt;
             out[idx] = rec;
@@ -1125,13 +1147,21 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// one key-space slice of a genome (the whole genome when the context has a single slice)
+struct Slice {
+    DevBuf keys, off, chunkstart, chunkdesc, ovf;   // ovf: u32 count @0, uint2 segments @16
+    u64 nmax = 0;            // exact key count of the slice (known after upload)
+    u32 nchunks = 0;
+    int64_t count = -1;      // key count confirmed by the sort
+};
+
 struct Genome {
     int id = -1;
     size_t n_bases = 0;
-    u64 nwords = 0;       // ceil(n/32)
-    u64 nmax = 0;         // upper bound of the key count
-    DevBuf bases, keys, off, chunkstart, chunkdesc, ovf;   // ovf: u32 count @0, uint2 segments @16
-    u32 nchunks = 0;
+    u64 nwords = 0;          // ceil(n/32)
+    u64 nmax = 0;            // sum of the slice counts
+    DevBuf bases;
+    std::vector<Slice> sl;
     bool uploaded = false, sorted = false, finalized = false;
     int64_t count = -1;
 };
@@ -1151,6 +1181,7 @@ struct kr_ctx {
     hipStream_t stream = nullptr;     // main stream = lanes[0].stream
     Lane lanes[MAX_LANES];
     int nlanes = 1, next_lane = 0;
+    int sb = 0, nslices = 1;          // key-space slices: 4^sb
     size_t budget = 0, used = 0;
     bool have_params = false;
     Geom g{};
@@ -1219,6 +1250,18 @@ static void release(kr_ctx* c, DevBuf& b) {
     }
     b.p = nullptr;
     b.bytes = 0;
+}
+
+static void release_genome(kr_ctx* c, Genome& G) {
+    release(c, G.bases);
+    for (Slice& S : G.sl) {
+        release(c, S.keys);
+        release(c, S.off);
+        release(c, S.chunkstart);
+        release(c, S.chunkdesc);
+        release(c, S.ovf);
+    }
+    G.sl.clear();
 }
 
 struct StageScope {
@@ -1327,14 +1370,7 @@ void kr_destroy(kr_ctx* c) {
         DevBuf* lb[] = {&ln.codes, &ln.bad, &ln.partial8, &ln.base1, &ln.tmpkeys, &ln.tp, &ln.tiledesc, &ln.tilehist};
         for (DevBuf* b : lb) release(c, *b);
     }
-    for (auto& kv : c->genomes) {
-        release(c, kv.second.bases);
-        release(c, kv.second.keys);
-        release(c, kv.second.off);
-        release(c, kv.second.chunkstart);
-        release(c, kv.second.chunkdesc);
-        release(c, kv.second.ovf);
-    }
+    for (auto& kv : c->genomes) release_genome(c, kv.second);
     DevBuf* all[] = {&c->candA, &c->candB, &c->chunkcnt,
                      &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec};
     for (DevBuf* b : all) release(c, *b);
@@ -1350,6 +1386,13 @@ void kr_destroy(kr_ctx* c) {
 
 static u64 topbits(int nbits) { return nbits <= 0 ? 0ull : (nbits >= 64 ? ~0ull : (~0ull << (64 - nbits))); }
 
+// geometry of slice `slice` (relative part) on top of the context's absolute geometry
+static Geom slice_geom(const kr_ctx* c, u32 slice) {
+    Geom g = c->g;
+    g.slice = slice;
+    return g;
+}
+
 int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_bases) {
     if (!c) return KR_ERR_PARAM;
     const int k = L + D + R;
@@ -1359,7 +1402,7 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     if (softmask_mode != KR_SOFT_MAP && softmask_mode != KR_SOFT_OMIT)
         return fail(c, KR_ERR_PARAM, "unknown softmask mode %d", softmask_mode);
     if (!c->genomes.empty()) return fail(c, KR_ERR_STATE, "kr_set_params after genomes were uploaded");
-    if (max_bases >= (1ull << 31)) return fail(c, KR_ERR_PARAM, "genomes of >= 2^31 bases need the chunked path");
+    if (max_bases >= (1ull << 32) - 64) return fail(c, KR_ERR_PARAM, "genomes of >= 2^32 bases are not supported");
     Geom g{};
     g.k = k; g.L = L; g.D = D; g.R = R;
     g.sR = 2 * D;
@@ -1368,12 +1411,29 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     g.mL = topbits(2 * L);
     g.mR = topbits(2 * (L + R)) & ~g.mL;
     g.mD = topbits(2 * k) & ~topbits(2 * (L + R));
-    g.pmask = topbits(2 * (L + R));
     g.omit = softmask_mode == KR_SOFT_OMIT;
+    // key-space slices: one sort unit holds at most ~4.2e8 keys (fine buckets of <= 1600 keys at the
+    // largest fan-out b = 18); larger genomes are sorted in 4^sb slices by the first sb bases of `left`
+    const u64 nmax = 2 * (u64)max_bases;
+    int sb = 0;
+    while (sb < 4 && (nmax >> (2 * sb)) > (1600ull << 18)) sb++;
+    if (const char* e = getenv("KR_SLICE_BASES")) sb = std::max(0, std::min(4, atoi(e)));
+    if (sb > L) {
+        if (getenv("KR_SLICE_BASES")) sb = L;
+        else return fail(c, KR_ERR_PARAM, "a genome of %zu bases needs %d slice bases but conserved-left is %d", max_bases, sb, L);
+    }
+    if ((nmax >> (2 * sb)) > (1600ull << 18) * 4)
+        return fail(c, KR_ERR_PARAM, "genome of %zu bases is too large for %d slice bases", max_bases, sb);
+    c->sb = sb;
+    c->nslices = 1 << (2 * sb);
+    g.sbits = 2 * sb;
+    g.slice = 0;
+    g.LRrel = L - sb + R;
+    g.pmask = topbits(2 * g.LRrel);
     // fan-out: average fine bucket of ~1600 keys or fewer (limit LS_CAP - LS_T = 2048), 8 <= b <= 18
-    u64 nmax = 2 * (u64)max_bases;
+    const u64 per_slice = nmax >> (2 * sb);
     int b = 8;
-    while (b < 18 && (nmax >> b) > 1600) b++;
+    while (b < 18 && (per_slice >> b) > 1600) b++;
     g.b = b;
     g.rb = 64 - b;
     c->g = g;
@@ -1382,42 +1442,93 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     return KR_OK;
 }
 
-int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
-    if (!c || !c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
-    if (n > c->max_bases) return fail(c, KR_ERR_PARAM, "genome of %zu bases exceeds max_bases %zu", n, c->max_bases);
-    HIPCHK(c, hipSetDevice(c->device));
-    Genome& G = c->genomes[id];
-    G.id = id;
-    G.n_bases = n;
-    G.nwords = (n + 31) / 32;
-    G.nmax = 2 * (u64)n;
-    G.sorted = G.finalized = false;
-    G.count = -1;
+static int alloc_slice(kr_ctx* c, Slice& S, u64 count) {
     const u32 nb = 1u << c->g.b;
-    G.nchunks = (u32)(G.nmax / LS_T) + 1;
+    S.nmax = count;
+    S.nchunks = (u32)(count / LS_T) + 1;
+    S.count = -1;
     int rc;
-    if ((rc = ensure(c, G.bases, n + 64))) return rc;
-    if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
-    if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
-    if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
-    if ((rc = ensure(c, G.chunkdesc, ((size_t)G.nchunks + 2) * 16))) return rc;
-    if ((rc = ensure(c, G.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
-    // per-lane scratch sized for the largest genome
+    if ((rc = ensure(c, S.keys, (count + 2) * 8))) return rc;
+    if ((rc = ensure(c, S.off, ((size_t)nb + 2) * 4))) return rc;
+    if ((rc = ensure(c, S.chunkstart, ((size_t)S.nchunks + 2) * 4))) return rc;
+    if ((rc = ensure(c, S.chunkdesc, ((size_t)S.nchunks + 2) * 16))) return rc;
+    if ((rc = ensure(c, S.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
+    return KR_OK;
+}
+
+// per-lane scratch for sorting slices of up to `maxcount` keys from genomes of up to max_bases
+static int ensure_lanes(kr_ctx* c, u64 maxcount) {
+    const u32 nb = 1u << c->g.b;
     const u64 mw = (c->max_bases + 31) / 32 + 4;
-    const u64 ntmax = 2 * (u64)c->max_bases / P2_TILE + 260;
+    const u64 ntmax = maxcount / P2_TILE + 260;
+    int rc;
     for (int i = 0; i < c->nlanes; i++) {
         Lane& ln = c->lanes[i];
         if ((rc = ensure(c, ln.codes, mw * 8))) return rc;
         if ((rc = ensure(c, ln.bad, mw * 4))) return rc;
         if ((rc = ensure(c, ln.partial8, (size_t)NWG * 256 * 4))) return rc;
         if ((rc = ensure(c, ln.base1, (260 + 256) * 4))) return rc;     // bases[257] | column totals[256]
-        if ((rc = ensure(c, ln.tmpkeys, (2 * (u64)c->max_bases + 2) * 8))) return rc;
+        if ((rc = ensure(c, ln.tmpkeys, (maxcount + 2) * 8))) return rc;
         if ((rc = ensure(c, ln.tp, 260 * 4))) return rc;
         if ((rc = ensure(c, ln.tiledesc, ntmax * 8))) return rc;
         if ((rc = ensure(c, ln.tilehist, ntmax * (nb >> 8) * 4))) return rc;
     }
-    if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KR_OK;
+}
+
+static void launch_pack(kr_ctx* c, Genome& G, Lane& ln, hipStream_t st) {
+    const u64 nwp = G.nwords + 2;   // two pad words (all bad) so window j may read word w+1
+    u32 grid = (u32)std::min<u64>((nwp + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, st, (const uint8_t*)G.bases.p, (u64)G.n_bases,
+                       (u64*)ln.codes.p, (u32*)ln.bad.p, nwp, c->g.omit);
+}
+
+int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
+    if (!c || !c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
+    if (n > c->max_bases) return fail(c, KR_ERR_PARAM, "genome of %zu bases exceeds max_bases %zu", n, c->max_bases);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    Genome& G = c->genomes[id];
+    G.id = id;
+    G.n_bases = n;
+    G.nwords = (n + 31) / 32;
+    G.sorted = G.finalized = false;
+    G.count = -1;
+    int rc;
+    if ((rc = ensure(c, G.bases, n + 64))) return rc;
+    if ((rc = ensure_lanes(c, 16))) return rc;
+    hipStream_t st = c->stream;
+    if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, st));
+    // exact key count of every slice (sizes the slice arrays): pack + top-byte histogram
+    Lane& ln = c->lanes[0];
+    launch_pack(c, G, ln, st);
+    if ((int)G.sl.size() != c->nslices) {
+        for (Slice& S : G.sl) {
+            release(c, S.keys); release(c, S.off); release(c, S.chunkstart); release(c, S.chunkdesc); release(c, S.ovf);
+        }
+        G.sl.assign(c->nslices, Slice());
+    }
+    std::vector<u32> tot(256);
+    u64 maxcount = 0;
+    G.nmax = 0;
+    for (int s = 0; s < c->nslices; s++) {
+        const Geom gs = slice_geom(c, (u32)s);
+        hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
+                           G.nwords, (u32*)ln.partial8.p, gs);
+        hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+        HIPCHK(c, hipMemcpyAsync(tot.data(), (u32*)ln.base1.p + 260, 256 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        u64 cnt = 0;
+        for (u32 v : tot) cnt += v;
+        if (cnt >= (1ull << 31))
+            return fail(c, KR_ERR_CAPACITY, "slice %d of genome %d holds %llu keys (>= 2^31): raise KR_SLICE_BASES", s,
+                        id, (unsigned long long)cnt);
+        if ((rc = alloc_slice(c, G.sl[s], cnt))) return rc;
+        G.nmax += cnt;
+        maxcount = std::max(maxcount, cnt);
+    }
+    HIPCHK(c, hipGetLastError());
+    if ((rc = ensure_lanes(c, maxcount))) return rc;
     G.uploaded = true;
     return KR_OK;
 }
@@ -1428,90 +1539,95 @@ int kr_genome_sort(kr_ctx* c, int id) {
     if (it == c->genomes.end() || !it->second.uploaded) return fail(c, KR_ERR_STATE, "genome %d not uploaded", id);
     HIPCHK(c, hipSetDevice(c->device));
     Genome& G = it->second;
-    const Geom g = c->g;
-    const u32 nb = 1u << g.b;
+    const u32 nb = 1u << c->g.b;
     Lane& ln = c->lanes[c->next_lane];
     c->next_lane = (c->next_lane + 1) % c->nlanes;
     ln.pending = true;
     hipStream_t st = ln.stream;
     u64* codes = (u64*)ln.codes.p;
     u32* bad = (u32*)ln.bad.p;
-    const u64 nwp = G.nwords + 2;   // two pad words (all bad) so window j may read word w+1
     G.sorted = G.finalized = false;
     G.count = -1;
     {
         StageScope sc(c, KR_ST_PACK, st);
-        u32 grid = (u32)std::min<u64>((nwp + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, st, (const uint8_t*)G.bases.p, (u64)G.n_bases, codes,
-                           bad, nwp, g.omit);
+        launch_pack(c, G, ln, st);
     }
-    {
-        StageScope sc(c, KR_ST_HIST8, st);
-        hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                           (u32*)ln.partial8.p, g);
-    }
-    {
-        StageScope sc(c, KR_ST_REDUCE8, st);
-        if (g.b > 8)
-            HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(G.nmax / P2_TILE) + 257) * 8, st));
-        hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
-        hipLaunchKernelGGL(k_reduce8b, dim3(1), dim3(1024), 0, st, (const u32*)ln.base1.p + 260,
-                           (u32*)ln.base1.p, (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
-    }
-    u64* pass1_dst = g.b > 8 ? (u64*)ln.tmpkeys.p : (u64*)G.keys.p;
-    {
-        StageScope sc(c, KR_ST_SCATTER1, st);
-        hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                           (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
-    }
-    if (g.b > 8) {
-        const u32 ntmax = (u32)(G.nmax / P2_TILE) + 257;
+    for (int s = 0; s < c->nslices; s++) {
+        Slice& S = G.sl[s];
+        const Geom g = slice_geom(c, (u32)s);
+        S.count = -1;
         {
-            StageScope sc(c, KR_ST_HIST2, st);
-            hipLaunchKernelGGL(k_hist2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
-                               (const uint2*)ln.tiledesc.p, (u32*)ln.tilehist.p, g.b);
+            StageScope sc(c, KR_ST_HIST8, st);
+            hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                               (u32*)ln.partial8.p, g);
         }
         {
-            StageScope sc(c, KR_ST_SCAN2, st);
-            hipLaunchKernelGGL(k_scan2, dim3(256), dim3(1024), 0, st, (u32*)ln.tilehist.p, (const u32*)ln.base1.p,
-                               (const u32*)ln.tp.p, (u32*)G.off.p, g.b);
+            StageScope sc(c, KR_ST_REDUCE8, st);
+            if (g.b > 8)
+                HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(S.nmax / P2_TILE) + 257) * 8, st));
+            hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+            hipLaunchKernelGGL(k_reduce8b, dim3(1), dim3(1024), 0, st, (const u32*)ln.base1.p + 260,
+                               (u32*)ln.base1.p, (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
+        }
+        u64* pass1_dst = g.b > 8 ? (u64*)ln.tmpkeys.p : (u64*)S.keys.p;
+        {
+            StageScope sc(c, KR_ST_SCATTER1, st);
+            hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                               (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
+        }
+        if (g.b > 8) {
+            const u32 ntmax = (u32)(S.nmax / P2_TILE) + 257;
+            {
+                StageScope sc(c, KR_ST_HIST2, st);
+                hipLaunchKernelGGL(k_hist2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
+                                   (const uint2*)ln.tiledesc.p, (u32*)ln.tilehist.p, g.b);
+            }
+            {
+                StageScope sc(c, KR_ST_SCAN2, st);
+                hipLaunchKernelGGL(k_scan2, dim3(256), dim3(1024), 0, st, (u32*)ln.tilehist.p, (const u32*)ln.base1.p,
+                                   (const u32*)ln.tp.p, (u32*)S.off.p, g.b);
+            }
+            {
+                StageScope sc(c, KR_ST_SCATTER2, st);
+                hipLaunchKernelGGL(k_scatter2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
+                                   (u64*)S.keys.p, (const uint2*)ln.tiledesc.p, (const u32*)ln.tilehist.p, g.b);
+            }
+        } else {
+            HIPCHK(c, hipMemcpyAsync(S.off.p, ln.base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
         }
         {
-            StageScope sc(c, KR_ST_SCATTER2, st);
-            hipLaunchKernelGGL(k_scatter2, dim3(ntmax), dim3(P2_T), 0, st, (const u64*)ln.tmpkeys.p,
-                               (u64*)G.keys.p, (const uint2*)ln.tiledesc.p, (const u32*)ln.tilehist.p, g.b);
+            StageScope sc(c, KR_ST_CHUNKS, st);
+            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)S.chunkstart.p, (int)nb, S.nchunks + 2, st));
+            hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)S.off.p, nb,
+                               (u32*)S.chunkstart.p);
+            hipLaunchKernelGGL(k_chunk_desc, dim3((S.nchunks + 255) / 256), dim3(256), 0, st, (const u32*)S.off.p,
+                               (const u32*)S.chunkstart.p, S.nchunks, (uint4*)S.chunkdesc.p);
         }
-    } else {
-        HIPCHK(c, hipMemcpyAsync(G.off.p, ln.base1.p, 257 * 4, hipMemcpyDeviceToDevice, st));
-    }
-    {
-        StageScope sc(c, KR_ST_CHUNKS, st);
-        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
-        hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
-                           (u32*)G.chunkstart.p);
-        hipLaunchKernelGGL(k_chunk_desc, dim3((G.nchunks + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p,
-                           (const u32*)G.chunkstart.p, G.nchunks, (uint4*)G.chunkdesc.p);
-    }
-    {
-        StageScope sc(c, KR_ST_LOCALSORT, st);
-        HIPCHK(c, hipMemsetAsync(G.ovf.p, 0, 16, st));
-        const u32 grid = std::min<u32>(G.nchunks, (u32)c->ls_grid);
-        hipLaunchKernelGGL(k_localsort, dim3(grid), dim3(LS_THREADS), 0, st, (u64*)G.keys.p,
-                           (const u32*)G.off.p, (const uint4*)G.chunkdesc.p, G.nchunks, g.b, (u32*)G.ovf.p,
-                           (uint2*)((char*)G.ovf.p + 16), c->dbg);
+        {
+            StageScope sc(c, KR_ST_LOCALSORT, st);
+            HIPCHK(c, hipMemsetAsync(S.ovf.p, 0, 16, st));
+            const u32 grid = std::min<u32>(S.nchunks, (u32)c->ls_grid);
+            hipLaunchKernelGGL(k_localsort, dim3(grid), dim3(LS_THREADS), 0, st, (u64*)S.keys.p,
+                               (const u32*)S.off.p, (const uint4*)S.chunkdesc.p, S.nchunks, g.b, (u32*)S.ovf.p,
+                               (uint2*)((char*)S.ovf.p + 16), c->dbg);
+        }
     }
     G.sorted = true;      // enqueued; oversized buckets (if any) are resolved by finalize()
     return KR_OK;
 }
 
-// Resolve what the asynchronous sort left open: the key count and -- rarely -- the
+// Resolve what the asynchronous sort left open: the key counts and -- rarely -- the
 // oversized buckets the LDS sort could not take (bitonic fallback in global memory).
 // One small D2H + sync for ALL listed genomes.
 static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
-    std::vector<Genome*> todo;
+    std::vector<Slice*> todo;
+    std::vector<Genome*> tg;
     for (Genome* G : gs)
-        if (G->sorted && !G->finalized) todo.push_back(G);
-    if (todo.empty()) return KR_OK;
+        if (G->sorted && !G->finalized) {
+            tg.push_back(G);
+            for (Slice& S : G->sl) todo.push_back(&S);
+        }
+    if (tg.empty()) return KR_OK;
     hipStream_t st = c->stream;
     {
         int rcj = join_lanes(c);
@@ -1526,12 +1642,12 @@ static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     for (size_t i = 0; i < todo.size(); i++) {
-        Genome& G = *todo[i];
-        G.count = total[i];
+        Slice& S = *todo[i];
+        S.count = total[i];
         if (novf[i]) {
             StageScope sc(c, KR_ST_FALLBACK);
             std::vector<uint2> segs;
-            uint2* dsegs = (uint2*)((char*)G.ovf.p + 16);
+            uint2* dsegs = (uint2*)((char*)S.ovf.p + 16);
             if (novf[i] > OVF_MAX) {
                 segs.push_back(make_uint2(0, total[i]));
                 HIPCHK(c, hipMemcpy(dsegs, segs.data(), 8, hipMemcpyHostToDevice));
@@ -1545,13 +1661,17 @@ static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
             dim3 grid(std::min<u32>((maxlen + 255) / 256, 65535), (u32)segs.size());
             for (u64 kk = 2; kk < 2ull * maxlen; kk <<= 1) {
                 for (u64 j = kk >> 1; j > 0; j >>= 1) {
-                    hipLaunchKernelGGL(k_bitonic_stage, grid, dim3(256), 0, st, (u64*)G.keys.p,
+                    hipLaunchKernelGGL(k_bitonic_stage, grid, dim3(256), 0, st, (u64*)S.keys.p,
                                        (const uint2*)dsegs, (u32)kk, (u32)j, j == (kk >> 1) ? 1 : 0);
                     c->fallback_launches++;
                 }
             }
         }
-        G.finalized = true;
+    }
+    for (Genome* G : tg) {
+        G->count = 0;
+        for (Slice& S : G->sl) G->count += S.count;
+        G->finalized = true;
     }
     return KR_OK;
 }
@@ -1560,29 +1680,52 @@ int64_t kr_genome_load_sorted(kr_ctx* c, int id, const uint64_t* keys, size_t n)
     if (!c || !c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
     if (n > 2 * c->max_bases) return fail(c, KR_ERR_PARAM, "%zu keys exceed 2 * max_bases", n);
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
     Genome& G = c->genomes[id];
     G.id = id;
     G.n_bases = 0;
     G.nwords = 0;
-    G.nmax = std::max<u64>(n, 1);
+    G.nmax = n;
+    for (Slice& S : G.sl) {
+        release(c, S.keys); release(c, S.off); release(c, S.chunkstart); release(c, S.chunkdesc); release(c, S.ovf);
+    }
+    G.sl.assign(c->nslices, Slice());
     const u32 nb = 1u << c->g.b;
-    G.nchunks = (u32)(G.nmax / LS_T) + 1;
-    int rc;
-    if ((rc = ensure(c, G.keys, (G.nmax + 2) * 8))) return rc;
-    if ((rc = ensure(c, G.off, ((size_t)nb + 2) * 4))) return rc;
-    if ((rc = ensure(c, G.chunkstart, ((size_t)G.nchunks + 2) * 4))) return rc;
-    if ((rc = ensure(c, G.chunkdesc, ((size_t)G.nchunks + 2) * 16))) return rc;
-    if ((rc = ensure(c, G.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
+    const int sbits = c->g.sbits;
     hipStream_t st = c->stream;
-    if (n) HIPCHK(c, hipMemcpyAsync(G.keys.p, keys, n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_offsets_from_sorted, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u64*)G.keys.p,
-                       (u32)n, nb, c->g.rb, (u32*)G.off.p);
-    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.chunkstart.p, (int)nb, G.nchunks + 2, st));
-    hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p, nb,
-                       (u32*)G.chunkstart.p);
-    hipLaunchKernelGGL(k_chunk_desc, dim3((G.nchunks + 255) / 256), dim3(256), 0, st, (const u32*)G.off.p,
-                       (const u32*)G.chunkstart.p, G.nchunks, (uint4*)G.chunkdesc.p);
-    HIPCHK(c, hipMemsetAsync(G.ovf.p, 0, 16, st));
+    size_t pos = 0;
+    std::vector<u64> rel;
+    for (int s = 0; s < c->nslices; s++) {
+        // the slice's keys are a contiguous run of the sorted input; store them relative
+        size_t end = n;
+        if (sbits && s + 1 < c->nslices) {
+            const u64 bound = (u64)(s + 1) << (64 - sbits);
+            end = std::lower_bound(keys + pos, keys + n, (uint64_t)bound) - keys;
+        }
+        const size_t cnt = end - pos;
+        Slice& S = G.sl[s];
+        int rc = alloc_slice(c, S, cnt);
+        if (rc) return rc;
+        if (cnt) {
+            const void* src = keys + pos;
+            if (sbits) {
+                rel.resize(cnt);
+                for (size_t i = 0; i < cnt; i++) rel[i] = (u64)keys[pos + i] << sbits;
+                src = rel.data();
+            }
+            HIPCHK(c, hipMemcpy(S.keys.p, src, cnt * 8, hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(k_offsets_from_sorted, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u64*)S.keys.p,
+                           (u32)cnt, nb, c->g.rb, (u32*)S.off.p);
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)S.chunkstart.p, (int)nb, S.nchunks + 2, st));
+        hipLaunchKernelGGL(k_chunk_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const u32*)S.off.p, nb,
+                           (u32*)S.chunkstart.p);
+        hipLaunchKernelGGL(k_chunk_desc, dim3((S.nchunks + 255) / 256), dim3(256), 0, st, (const u32*)S.off.p,
+                           (const u32*)S.chunkstart.p, S.nchunks, (uint4*)S.chunkdesc.p);
+        HIPCHK(c, hipMemsetAsync(S.ovf.p, 0, 16, st));
+        S.count = (int64_t)cnt;
+        pos = end;
+    }
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     G.uploaded = false;
@@ -1615,7 +1758,19 @@ int64_t kr_genome_fetch_keys(kr_ctx* c, int id, uint64_t* out, size_t cap) {
     if (n < 0) return n;
     if ((size_t)n > cap) return fail(c, KR_ERR_CAPACITY, "key buffer too small: %lld > %zu", (long long)n, cap);
     Genome& G = c->genomes[id];
-    if (n) HIPCHK(c, hipMemcpy(out, G.keys.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipDeviceSynchronize());
+    const int sbits = c->g.sbits;
+    size_t pos = 0;
+    for (int s = 0; s < c->nslices; s++) {
+        Slice& S = G.sl[s];
+        const size_t cnt = (size_t)S.count;
+        if (cnt) HIPCHK(c, hipMemcpy(out + pos, S.keys.p, cnt * 8, hipMemcpyDeviceToHost));
+        if (sbits) {      // relative -> absolute
+            const u64 top = (u64)s << (64 - sbits);
+            for (size_t i = 0; i < cnt; i++) out[pos + i] = top | (out[pos + i] >> sbits);
+        }
+        pos += cnt;
+    }
     return n;
 }
 
@@ -1624,12 +1779,7 @@ int kr_genome_free(kr_ctx* c, int id) {
     auto it = c->genomes.find(id);
     if (it == c->genomes.end()) return fail(c, KR_ERR_PARAM, "unknown genome %d", id);
     (void)hipDeviceSynchronize();
-    release(c, it->second.bases);
-    release(c, it->second.keys);
-    release(c, it->second.off);
-    release(c, it->second.chunkstart);
-    release(c, it->second.chunkdesc);
-    release(c, it->second.ovf);
+    release_genome(c, it->second);
     c->genomes.erase(it);
     return KR_OK;
 }
@@ -1638,57 +1788,69 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     if (!c || n < 1) return fail(c, KR_ERR_PARAM, "kr_intersect: need at least one genome");
     if (n > MAXG) return fail(c, KR_ERR_PARAM, "kr_intersect: at most %d genomes per call (cascade with kr_cands_merge)", MAXG);
     HIPCHK(c, hipSetDevice(c->device));
-    IsectArgs a{};
-    int rc0;
-    a.n = n;
-    a.ingroup_bits = 0;
-    a.apply_filter = apply_filter ? 1 : 0;
-    a.dbg = c->dbg;
     int anchor = 0;
     u64 best = ~0ull;
+    u32 ingroup_bits = 0;
     std::vector<Genome*> gs;
     for (int i = 0; i < n; i++) {
         auto it = c->genomes.find(ids[i]);
         if (it == c->genomes.end() || !it->second.sorted) return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
         Genome& G = it->second;
-        a.keys[i] = (const u64*)G.keys.p;
-        a.off[i] = (const u32*)G.off.p;
-        if (is_in[i]) a.ingroup_bits |= 1u << i;
+        if (is_in[i]) ingroup_bits |= 1u << i;
         if (G.nmax < best) { best = G.nmax; anchor = i; }
         gs.push_back(&G);
     }
-    if ((rc0 = finalize(c, gs))) return rc0;
-    Genome& A = *gs[anchor];
-    a.anchor = anchor;
-    a.chunkdesc = (const uint4*)A.chunkdesc.p;
     int rc;
-    if ((rc = ensure(c, c->candA, (A.nmax + 2) * sizeof(kr_cand)))) return rc;
-    if ((rc = ensure(c, c->candB, (A.nmax + 2) * sizeof(kr_cand)))) return rc;
-    if ((rc = ensure(c, c->chunkcnt, ((size_t)A.nchunks + 2) * 4))) return rc;
-    if ((rc = ensure(c, c->chunkpos, ((size_t)A.nchunks + 2) * 4))) return rc;
-    a.tmp = (kr_cand*)c->candA.p;
-    a.chunkcnt = (u32*)c->chunkcnt.p;
+    if ((rc = finalize(c, gs))) return rc;
+    Genome& A = *gs[anchor];
+    u64 amax = 0;
+    u32 cmax = 0;
+    for (Slice& S : A.sl) { amax = std::max(amax, S.nmax); cmax = std::max(cmax, S.nchunks); }
+    if ((rc = ensure(c, c->candA, (amax + 2) * sizeof(kr_cand)))) return rc;      // per-slice sparse runs
+    if ((rc = ensure(c, c->candB, (A.nmax + 2) * sizeof(kr_cand)))) return rc;    // dense result, all slices
+    if ((rc = ensure(c, c->chunkcnt, ((size_t)cmax + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->chunkpos, ((size_t)cmax + 2) * 4))) return rc;
     hipStream_t st = c->stream;
-    {
-        StageScope sc(c, KR_ST_INTERSECT);
-        if (c->g.D > 8)
-            hipLaunchKernelGGL(k_intersect<true>, dim3(A.nchunks), dim3(IS_THREADS), 0, st, a, c->g);
-        else
-            hipLaunchKernelGGL(k_intersect<false>, dim3(A.nchunks), dim3(IS_THREADS), 0, st, a, c->g);
+    u64 running = 0;
+    for (int s = 0; s < c->nslices; s++) {
+        const Geom g = slice_geom(c, (u32)s);
+        Slice& AS = A.sl[s];
+        IsectArgs a{};
+        a.n = n;
+        a.ingroup_bits = ingroup_bits;
+        a.apply_filter = apply_filter ? 1 : 0;
+        a.dbg = c->dbg;
+        a.anchor = anchor;
+        for (int i = 0; i < n; i++) {
+            a.keys[i] = (const u64*)gs[i]->sl[s].keys.p;
+            a.off[i] = (const u32*)gs[i]->sl[s].off.p;
+        }
+        a.chunkdesc = (const uint4*)AS.chunkdesc.p;
+        a.tmp = (kr_cand*)c->candA.p;
+        a.chunkcnt = (u32*)c->chunkcnt.p;
+        {
+            StageScope sc(c, KR_ST_INTERSECT);
+            if (g.D > 8)
+                hipLaunchKernelGGL(k_intersect<true>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
+            else
+                hipLaunchKernelGGL(k_intersect<false>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
+        }
+        {
+            StageScope sc(c, KR_ST_COMPACT);
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->chunkcnt.p, (u32*)c->chunkpos.p,
+                               AS.nchunks);
+            hipLaunchKernelGGL(k_gather_cands, dim3(AS.nchunks), dim3(64), 0, st, g.sbits, g.slice,
+                               (const kr_cand*)c->candA.p, (const uint4*)AS.chunkdesc.p, (const u32*)c->chunkcnt.p,
+                               (const u32*)c->chunkpos.p, (kr_cand*)c->candB.p + running);
+        }
+        u32 total = 0;
+        HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->chunkpos.p + AS.nchunks, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+        running += total;
     }
-    {
-        StageScope sc(c, KR_ST_COMPACT);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->chunkcnt.p, (u32*)c->chunkpos.p, A.nchunks);
-        hipLaunchKernelGGL(k_gather_cands, dim3(A.nchunks), dim3(64), 0, st, (const kr_cand*)c->candA.p,
-                           (const uint4*)A.chunkdesc.p, (const u32*)c->chunkcnt.p,
-                           (const u32*)c->chunkpos.p, (kr_cand*)c->candB.p);
-    }
-    u32 total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->chunkpos.p + A.nchunks, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
-    c->ncand = total;
-    return total;
+    c->ncand = (int64_t)running;
+    return c->ncand;
 }
 
 int64_t kr_cands_count(kr_ctx* c) { return c ? c->ncand : KR_ERR_PARAM; }
@@ -1756,28 +1918,26 @@ int64_t kr_collect(kr_ctx* c, const int* ids, int n) {
     const u32 nc = (u32)c->ncand;
     c->nrecords = 0;
     if (nc == 0 || n == 0) return 0;
-    {
-        std::vector<Genome*> gs;
-        for (int i = 0; i < n; i++) {
-            auto it = c->genomes.find(ids[i]);
-            if (it == c->genomes.end() || !it->second.sorted)
-                return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
-            gs.push_back(&it->second);
-        }
-        if ((rc = finalize(c, gs))) return rc;
+    std::vector<Genome*> gs;
+    for (int i = 0; i < n; i++) {
+        auto it = c->genomes.find(ids[i]);
+        if (it == c->genomes.end() || !it->second.sorted)
+            return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
+        gs.push_back(&it->second);
     }
+    if ((rc = finalize(c, gs))) return rc;
     for (int pass = 0; pass < 2; pass++) {
         HIPCHK(c, hipMemsetAsync(c->nrec.p, 0, 16, st));
         StageScope sc(c, KR_ST_COLLECT);
         for (int i = 0; i < n; i++) {
-            auto it = c->genomes.find(ids[i]);
-            if (it == c->genomes.end() || !it->second.sorted)
-                return fail(c, KR_ERR_STATE, "genome %d not sorted", ids[i]);
-            Genome& G = it->second;
-            hipLaunchKernelGGL(k_collect, dim3((nc + 127) / 128), dim3(128), 0, st, (const kr_cand*)c->candB.p, nc,
-                               (const u64*)G.keys.p, (const u32*)G.off.p, c->g, (u32)ids[i],
-                               pass ? (kr_record*)c->records.p : (kr_record*)nullptr,
-                               pass ? (u64)(c->records.bytes / sizeof(kr_record)) : 0ull, (u64*)c->nrec.p);
+            for (int s = 0; s < c->nslices; s++) {
+                Slice& S = gs[i]->sl[s];
+                if (S.count == 0) continue;
+                hipLaunchKernelGGL(k_collect, dim3((nc + 127) / 128), dim3(128), 0, st, (const kr_cand*)c->candB.p,
+                                   nc, (const u64*)S.keys.p, (const u32*)S.off.p, slice_geom(c, (u32)s), (u32)ids[i],
+                                   pass ? (kr_record*)c->records.p : (kr_record*)nullptr,
+                                   pass ? (u64)(c->records.bytes / sizeof(kr_record)) : 0ull, (u64*)c->nrec.p);
+            }
         }
         u64 total = 0;
         HIPCHK(c, hipMemcpyAsync(&total, c->nrec.p, 8, hipMemcpyDeviceToHost, st));
@@ -1866,15 +2026,17 @@ int64_t kr_debug_fetch(kr_ctx* c, int id, int what, void* out, size_t cap_bytes)
     const u32 nb = 1u << c->g.b;
     const void* src = nullptr;
     size_t esz = 8, n = 0;
+    if (G.sl.empty()) return fail(c, KR_ERR_STATE, "genome %d has no slices", id);
+    Slice& S0 = G.sl[c->nslices - 1];      // the slice sorted last (its scratch is still in the lane)
     u32 total = 0;
-    HIPCHK(c, hipMemcpy(&total, (u32*)G.off.p + nb, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&total, (u32*)S0.off.p + nb, 4, hipMemcpyDeviceToHost));
     switch (what) {
     case 0: src = ln.codes.p; esz = 8; n = G.nwords + 2; break;
     case 1: src = ln.bad.p; esz = 4; n = G.nwords + 2; break;
     case 2: src = ln.base1.p; esz = 4; n = 257; break;
-    case 3: src = G.off.p; esz = 4; n = nb + 1; break;
-    case 4: src = c->g.b > 8 ? ln.tmpkeys.p : G.keys.p; esz = 8; n = total; break;
-    case 5: src = G.keys.p; esz = 8; n = total; break;
+    case 3: src = S0.off.p; esz = 4; n = nb + 1; break;
+    case 4: src = c->g.b > 8 ? ln.tmpkeys.p : S0.keys.p; esz = 8; n = total; break;
+    case 5: src = S0.keys.p; esz = 8; n = total; break;
     default: return fail(c, KR_ERR_PARAM, "kr_debug_fetch: unknown selector %d", what);
     }
     if (n * esz > cap_bytes) return fail(c, KR_ERR_CAPACITY, "debug buffer too small");
@@ -1891,7 +2053,7 @@ int kr_debug_info(kr_ctx* c, int64_t* o) {
     o[4] = NWG;
     o[5] = c->overflow_segments;
     o[6] = c->fallback_launches;
-    o[7] = (int64_t)c->used;
+    o[7] = (int64_t)c->nslices;
     return KR_OK;
 }
 

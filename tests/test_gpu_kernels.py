@@ -37,7 +37,7 @@ def _check_sorted(N, K, text, L, D, R, omit=False, stages=False):
         e.sort(0)
         info = e.debug_info()
         assert e.count(0) == len(want), info
-        if stages:
+        if stages and info["nslices"] == 1:
             b = info["b"]
             top = (want >> np.uint64(64 - b)).astype(np.int64)
             hist = np.bincount(top, minlength=1 << b).astype(np.uint32)
@@ -104,6 +104,15 @@ def test_sort_skewed_genome_overflow_fallback(N, K):
     text = np.concatenate(parts)
     info = _check_sorted(N, K, text, 25, 1, 2)
     assert info["overflow_segments"] >= 1 and info["fallback_launches"] > 0
+
+
+def test_key_space_slices_report(N):
+    """KR_SLICE_BASES=n forces 4^n key-space slices (the large-genome path) through every test."""
+    import os
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=1000)
+        want = 4 ** int(os.environ.get("KR_SLICE_BASES", "0"))
+        assert e.debug_info()["nslices"] == want
 
 
 def _family(seed, n, length, mu=0.01):
