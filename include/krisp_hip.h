@@ -133,6 +133,8 @@ int64_t kr_stage_launches(kr_ctx*, int stage);
  * 3 bucket offsets(u32) 4 keys after pass 1 5 keys after pass 2.  Returns the
  * number of ELEMENTS copied (of the element type above). */
 int64_t kr_debug_fetch(kr_ctx*, int genome_id, int what, void* out, size_t cap_bytes);
+/* property check for sizes no oracle reaches: adjacent key pairs out of order (0 = sorted) */
+int64_t kr_debug_inversions(kr_ctx*, int genome_id);
 int     kr_debug_info(kr_ctx*, int64_t* out8);  /* b, nbuckets, T, CAP, nwg, overflow segments, fallback launches, 0 */
 
 #ifdef __cplusplus

@@ -55,6 +55,7 @@ SYMBOLS = [
     ("kr_stage_ms", _c.c_double, [_P, _c.c_int]),
     ("kr_stage_launches", _c.c_int64, [_P, _c.c_int]),
     ("kr_debug_fetch", _c.c_int64, [_P, _c.c_int, _c.c_int, _P, _c.c_size_t]),
+    ("kr_debug_inversions", _c.c_int64, [_P, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
 ]
 
@@ -220,6 +221,9 @@ class Engine:
         self.lib.kr_debug_info(self.ctx, _ptr(o))
         return dict(b=int(o[0]), nbuckets=int(o[1]), T=int(o[2]), CAP=int(o[3]), nwg=int(o[4]),
                     overflow_segments=int(o[5]), fallback_launches=int(o[6]), nslices=int(o[7]))
+
+    def inversions(self, gid):
+        return self._check(self.lib.kr_debug_inversions(self.ctx, gid), "kr_debug_inversions")
 
     def debug_fetch(self, gid, what, n_max):
         dt = {0: np.uint64, 1: np.uint32, 2: np.uint32, 3: np.uint32, 4: np.uint64, 5: np.uint64}[what]

@@ -540,6 +540,15 @@ __global__ void k_chunk_desc(const u32* __restrict__ off, const u32* __restrict_
     desc[j] = d;
 }
 
+// property check for full-size runs: number of adjacent pairs out of order
+__global__ void k_count_inversions(const u64* __restrict__ keys, u64 n, u64* __restrict__ out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 bad = 0;
+    for (; i + 1 < n; i += stride) bad += keys[i] > keys[i + 1];
+    if (bad) atomicAdd(out, (u64)bad);
+}
+
 // fine bucket offsets of an already sorted key array: off[f] = lower_bound(f << rb)
 __global__ void k_offsets_from_sorted(const u64* __restrict__ keys, u32 n, u32 nb, int rb, u32* __restrict__ off) {
     u32 f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1243,6 +1252,25 @@ static int ensure(kr_ctx* c, DevBuf& b, size_t bytes) {
     return KR_OK;
 }
 
+// grow a buffer that holds live data: contents are preserved
+static int ensure_keep(kr_ctx* c, DevBuf& b, size_t bytes, size_t live_bytes) {
+    if (b.bytes >= bytes) return KR_OK;
+    size_t want = std::max(bytes, b.bytes * 2);
+    DevBuf nb;
+    int rc = ensure(c, nb, want);
+    if (rc) return rc;
+    if (b.p && live_bytes) {
+        hipError_t e = hipMemcpy(nb.p, b.p, live_bytes, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) return fail(c, KR_ERR_HIP, "hipMemcpy D2D failed: %s", hipGetErrorString(e));
+    }
+    if (b.p) {
+        (void)hipFree(b.p);
+        c->used -= b.bytes;
+    }
+    b = nb;
+    return KR_OK;
+}
+
 static void release(kr_ctx* c, DevBuf& b) {
     if (b.p) {
         (void)hipFree(b.p);
@@ -1807,7 +1835,7 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
     u32 cmax = 0;
     for (Slice& S : A.sl) { amax = std::max(amax, S.nmax); cmax = std::max(cmax, S.nchunks); }
     if ((rc = ensure(c, c->candA, (amax + 2) * sizeof(kr_cand)))) return rc;      // per-slice sparse runs
-    if ((rc = ensure(c, c->candB, (A.nmax + 2) * sizeof(kr_cand)))) return rc;    // dense result, all slices
+    if ((rc = ensure(c, c->candB, 4096 * sizeof(kr_cand)))) return rc;            // dense result: grows as needed
     if ((rc = ensure(c, c->chunkcnt, ((size_t)cmax + 2) * 4))) return rc;
     if ((rc = ensure(c, c->chunkpos, ((size_t)cmax + 2) * 4))) return rc;
     hipStream_t st = c->stream;
@@ -1835,20 +1863,26 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
             else
                 hipLaunchKernelGGL(k_intersect<false>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
         }
+        u32 total = 0;
         {
             StageScope sc(c, KR_ST_COMPACT);
             hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)c->chunkcnt.p, (u32*)c->chunkpos.p,
                                AS.nchunks);
-            hipLaunchKernelGGL(k_gather_cands, dim3(AS.nchunks), dim3(64), 0, st, g.sbits, g.slice,
-                               (const kr_cand*)c->candA.p, (const uint4*)AS.chunkdesc.p, (const u32*)c->chunkcnt.p,
-                               (const u32*)c->chunkpos.p, (kr_cand*)c->candB.p + running);
+            HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->chunkpos.p + AS.nchunks, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipGetLastError());
+            if ((rc = ensure_keep(c, c->candB, (running + total + 2) * sizeof(kr_cand), running * sizeof(kr_cand))))
+                return rc;
+            if (total)
+                hipLaunchKernelGGL(k_gather_cands, dim3(AS.nchunks), dim3(64), 0, st, g.sbits, g.slice,
+                                   (const kr_cand*)c->candA.p, (const uint4*)AS.chunkdesc.p,
+                                   (const u32*)c->chunkcnt.p, (const u32*)c->chunkpos.p,
+                                   (kr_cand*)c->candB.p + running);
         }
-        u32 total = 0;
-        HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->chunkpos.p + AS.nchunks, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        HIPCHK(c, hipGetLastError());
         running += total;
     }
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
     c->ncand = (int64_t)running;
     return c->ncand;
 }
@@ -2042,6 +2076,25 @@ int64_t kr_debug_fetch(kr_ctx* c, int id, int what, void* out, size_t cap_bytes)
     if (n * esz > cap_bytes) return fail(c, KR_ERR_CAPACITY, "debug buffer too small");
     if (n) HIPCHK(c, hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost));
     return (int64_t)n;
+}
+
+int64_t kr_debug_inversions(kr_ctx* c, int id) {
+    if (!c) return KR_ERR_PARAM;
+    auto it = c->genomes.find(id);
+    if (it == c->genomes.end() || !it->second.sorted) return fail(c, KR_ERR_STATE, "genome %d not sorted", id);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finalize(c, {&it->second});
+    if (rc) return rc;
+    if ((rc = ensure(c, c->nrec, 16))) return rc;
+    HIPCHK(c, hipMemset(c->nrec.p, 0, 16));
+    for (Slice& S : it->second.sl)
+        if (S.count > 1)
+            hipLaunchKernelGGL(k_count_inversions, dim3(4096), dim3(256), 0, c->stream, (const u64*)S.keys.p,
+                               (u64)S.count, (u64*)c->nrec.p);
+    u64 bad = 0;
+    HIPCHK(c, hipMemcpy(&bad, c->nrec.p, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipGetLastError());
+    return (int64_t)bad;
 }
 
 int kr_debug_info(kr_ctx* c, int64_t* o) {

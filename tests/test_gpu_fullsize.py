@@ -1,0 +1,102 @@
+"""Full-size runs checked through size-independent properties (no oracle reaches these
+sizes in seconds): record count = 2 x valid windows, sortedness (adjacent inversions
+counted on the device), idempotence of sort + intersect, every candidate re-found by the
+collect in every genome, agreement between slicing configurations.
+
+  * BASELINE configs[1] (4 x 50 Mbp, 25/1/2) runs in the regular `-m gpu` suite.
+  * BASELINE configs[4] (2 x 3 Gbp, k = 31 as 28/1/2; 16 key-space slices, ~100 GB of HBM)
+    is opt-in: KR_RUN_C5=1 (minutes of host-side genome generation).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _family(config, n_in, n_out, length):
+    from krisp_amd import synth
+    return synth.family(config, n_in, n_out, length, records=16, mu=0.01, snp_every=10000)
+
+
+def _valid_windows(text, k):
+    seps = np.flatnonzero(text == 10)
+    bounds = np.concatenate([[-1], seps, [len(text)]])
+    lens = np.diff(bounds) - 1
+    return int(np.maximum(lens - k + 1, 0).sum())
+
+
+def _run(fam, L, D, R, slice_bases=None):
+    from krisp_amd import _native
+    old = os.environ.get("KR_SLICE_BASES")
+    if slice_bases is not None:
+        os.environ["KR_SLICE_BASES"] = str(slice_bases)
+    try:
+        eng = _native.Engine()
+        eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+    finally:
+        if slice_bases is not None:
+            if old is None:
+                del os.environ["KR_SLICE_BASES"]
+            else:
+                os.environ["KR_SLICE_BASES"] = old
+    ids = list(range(len(fam)))
+    flags = [f for _, f, _ in fam]
+    for i, (_, _, t) in enumerate(fam):
+        eng.upload(i, t)
+    for i in ids:
+        eng.sort(i)
+    n1 = eng.intersect(ids, flags, apply_filter=True)
+    c1 = eng.cands().copy()
+    for i, (_, _, t) in enumerate(fam):
+        assert eng.count(i) == 2 * _valid_windows(t, L + D + R)
+        assert eng.inversions(i) == 0
+    # idempotence: sorting again from the resident bases and intersecting again changes nothing
+    for i in ids:
+        eng.sort(i)
+    assert eng.intersect(ids, flags, apply_filter=True) == n1
+    c2 = eng.cands()
+    assert np.array_equal(c1, c2)
+    assert np.all(np.diff(c1["prefix"].astype(np.uint64)) > 0) if n1 > 1 else True
+    # every candidate is present in every genome, and ingroup / outgroup diagnostic bases differ
+    recs = eng.collect(ids)
+    pm = np.uint64((~0 << (64 - 2 * (L + R))) & 0xFFFFFFFFFFFFFFFF)
+    pre = recs["key"] & pm
+    for i in ids:
+        assert np.array_equal(np.unique(pre[recs["genome"] == i]), c1["prefix"])
+    if D == 1:
+        dshift = np.uint64(62 - 2 * (L + R))
+        base = ((recs["key"] >> dshift) & np.uint64(3)).astype(np.int64)
+        is_in = np.array(flags)[recs["genome"]]
+        order = np.argsort(pre, kind="stable")
+        idx = np.searchsorted(c1["prefix"], pre)
+        in_sets = np.zeros(n1, dtype=np.int64)
+        out_sets = np.zeros(n1, dtype=np.int64)
+        np.bitwise_or.at(in_sets, idx[is_in], 1 << base[is_in])
+        np.bitwise_or.at(out_sets, idx[~is_in], 1 << base[~is_in])
+        assert np.all((in_sets & out_sets) == 0)
+        assert np.array_equal(in_sets, c1["in_mask"].astype(np.int64))
+        assert np.array_equal(out_sets, c1["out_mask"].astype(np.int64))
+    info = eng.debug_info()
+    eng.close()
+    return c1, info
+
+
+def test_c2_full_size_properties():
+    fam = _family(2, 2, 2, 50_000_000)
+    c1, info = _run(fam, 25, 1, 2)
+    assert info["nslices"] == 1 and info["overflow_segments"] == 0
+    assert len(c1) > 1000
+    # the same workload through 4 key-space slices gives the same candidates
+    c4, info4 = _run(fam, 25, 1, 2, slice_bases=1)
+    assert info4["nslices"] == 4
+    assert np.array_equal(c1, c4)
+
+
+@pytest.mark.skipif(os.environ.get("KR_RUN_C5") != "1", reason="opt-in: KR_RUN_C5=1 (2 x 3 Gbp, ~100 GB HBM)")
+def test_c5_three_gbp_genomes():
+    fam = _family(5, 1, 1, 3_000_000_000)
+    c1, info = _run(fam, 28, 1, 2)
+    assert info["nslices"] == 16
+    print("C5:", len(c1), "candidates;", info)
