@@ -590,7 +590,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
                                                           const u32* __restrict__ off,
                                                           const uint4* __restrict__ desc, u32 nchunks, int b,
                                                           u32* __restrict__ ovf_count,
-                                                          uint2* __restrict__ ovf_list, int dbg) {
+                                                          uint4* __restrict__ ovf_list, int dbg) {
     __shared__ __attribute__((aligned(16))) u64 S[LS_CAP];
     __shared__ u32 cnt[LS_NB / 2];
     __shared__ u32 waves[17];
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
             u32 ls = off[last];
             if (tid == 0) {
                 u32 idx = atomicAdd(ovf_count, 1u);
-                if (idx < OVF_MAX) ovf_list[idx] = make_uint2(ls, e);
+                if (idx < OVF_MAX) ovf_list[idx] = make_uint4(ls, e, last, 0);
             }
             hi = last;
             e = ls;
@@ -717,22 +717,88 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
 }
 
 // ----------------------------------------------------------------------------
-// Kb  one (k, j) stage of an all-ascending bitonic network over arbitrary-length
-// segments (flip on the first step of a merge, disperse after): the robust
-// fallback for buckets that do not fit the LDS sort.  grid.y = segment.
+// Kb  fallback for fine buckets that do not fit the LDS sort (poly-A, satellites, tandem
+// repeats): their 4096-key tiles are sorted by k_localsort itself (descriptor list of
+// tiles), then merged pairwise -- run length doubling each round -- by a merge-path kernel:
+// one workgroup per 2048 output keys finds its two input ranges by binary search, stages
+// them in LDS, every thread merges 8 outputs.  Source -> scratch, then copied back.
+// segs[i] = {start, end, first global tile of the segment, 0}
 // ----------------------------------------------------------------------------
-__global__ void k_bitonic_stage(u64* __restrict__ keys, const uint2* __restrict__ segs, u32 kk, u32 j,
-                                int flip) {
-    uint2 sg = segs[blockIdx.y];
-    u32 n = sg.y - sg.x;
-    u64* a = keys + sg.x;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        u32 p = flip ? (i ^ (kk - 1)) : (i ^ j);
-        if (p > i && p < n) {
-            u64 x = a[i], y = a[p];
-            if (x > y) { a[i] = y; a[p] = x; }
+#define MG_T 256
+#define MG_VT 8
+#define MG_TILE (MG_T * MG_VT)
+
+__device__ __forceinline__ u32 merge_path(const u64* A, u32 na, const u64* B, u32 nb, u32 diag) {
+    u32 lo = diag > nb ? diag - nb : 0, hi = diag < na ? diag : na;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (A[mid] <= B[diag - mid - 1]) lo = mid + 1; else hi = mid;
+    }
+    return lo;      // number of A elements among the first `diag` merged (ties: A first)
+}
+
+__global__ __launch_bounds__(MG_T) void k_seg_merge(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                    const uint4* __restrict__ segs, u32 nseg, u32 run) {
+    __shared__ __attribute__((aligned(16))) u64 L[MG_TILE];
+    __shared__ u32 sh[4];
+    const u32 tile = blockIdx.x;
+    u32 lo = 0, hi = nseg;                      // last segment whose first tile is <= tile
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (segs[mid].z <= tile) lo = mid; else hi = mid;
+    }
+    const uint4 sg = segs[lo];
+    const u32 len = sg.y - sg.x;
+    const u32 o0 = (tile - sg.z) * MG_TILE;
+    if (o0 >= len) return;
+    const u32 o1 = min(o0 + MG_TILE, len);
+    const u32 base = (o0 / (2 * run)) * (2 * run);
+    const u32 amid = min(base + run, len), bend = min(base + 2 * run, len);
+    const u64* A = src + sg.x + base;
+    const u64* B = src + sg.x + amid;
+    const u32 na = amid - base, nb = bend - amid;
+    if (threadIdx.x == 0) {
+        sh[0] = merge_path(A, na, B, nb, o0 - base);
+        sh[1] = merge_path(A, na, B, nb, o1 - base);
+    }
+    __syncthreads();
+    const u32 a0 = sh[0], a1 = sh[1];
+    const u32 b0 = (o0 - base) - a0, b1 = (o1 - base) - a1;
+    const u32 ca = a1 - a0, cb = b1 - b0;
+    for (u32 i = threadIdx.x; i < ca; i += MG_T) L[i] = A[a0 + i];
+    for (u32 i = threadIdx.x; i < cb; i += MG_T) L[ca + i] = B[b0 + i];
+    __syncthreads();
+    const u64* LA = L;
+    const u64* LB = L + ca;
+    const u32 total = ca + cb;
+    const u32 d = min(threadIdx.x * MG_VT, total);
+    u32 ia = merge_path(LA, ca, LB, cb, d);
+    u32 ib = d - ia;
+    u64* out = dst + sg.x + o0;
+#pragma unroll
+    for (int q = 0; q < MG_VT; q++) {
+        u32 o = d + q;
+        if (o < total) {
+            bool takeA = ib >= cb || (ia < ca && LA[ia] <= LB[ib]);
+            out[o] = takeA ? LA[ia] : LB[ib];
+            ia += takeA;
+            ib += !takeA;
         }
     }
+}
+
+__global__ void k_seg_copy(const u64* __restrict__ src, u64* __restrict__ dst, const uint4* __restrict__ segs,
+                           u32 nseg) {
+    const u32 tile = blockIdx.x;
+    u32 lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (segs[mid].z <= tile) lo = mid; else hi = mid;
+    }
+    const uint4 sg = segs[lo];
+    const u32 len = sg.y - sg.x;
+    const u32 o0 = (tile - sg.z) * MG_TILE;
+    for (u32 i = o0 + threadIdx.x; i < min(o0 + MG_TILE, len); i += blockDim.x) dst[sg.x + i] = src[sg.x + i];
 }
 
 // ----------------------------------------------------------------------------
@@ -1198,7 +1264,7 @@ struct kr_ctx {
     std::map<int, Genome> genomes;
     int ls_grid = 768;     // resident k_localsort workgroups (set from the occupancy query)
     // candidates / records
-    DevBuf candA, candB, chunkcnt, chunkpos, flags, blockcnt, blockpos, other, records, nrec;
+    DevBuf candA, candB, chunkcnt, chunkpos, flags, blockcnt, blockpos, other, records, nrec, fbdesc, fbsegs;
     int64_t ncand = -1;
     int64_t nrecords = 0;
     std::string err;
@@ -1400,7 +1466,7 @@ void kr_destroy(kr_ctx* c) {
     }
     for (auto& kv : c->genomes) release_genome(c, kv.second);
     DevBuf* all[] = {&c->candA, &c->candB, &c->chunkcnt,
-                     &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec};
+                     &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec, &c->fbdesc, &c->fbsegs};
     for (DevBuf* b : all) release(c, *b);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->t0);
@@ -1480,7 +1546,7 @@ static int alloc_slice(kr_ctx* c, Slice& S, u64 count) {
     if ((rc = ensure(c, S.off, ((size_t)nb + 2) * 4))) return rc;
     if ((rc = ensure(c, S.chunkstart, ((size_t)S.nchunks + 2) * 4))) return rc;
     if ((rc = ensure(c, S.chunkdesc, ((size_t)S.nchunks + 2) * 16))) return rc;
-    if ((rc = ensure(c, S.ovf, 16 + (size_t)OVF_MAX * 8))) return rc;
+    if ((rc = ensure(c, S.ovf, 16 + (size_t)OVF_MAX * 16))) return rc;
     return KR_OK;
 }
 
@@ -1637,7 +1703,7 @@ int kr_genome_sort(kr_ctx* c, int id) {
             const u32 grid = std::min<u32>(S.nchunks, (u32)c->ls_grid);
             hipLaunchKernelGGL(k_localsort, dim3(grid), dim3(LS_THREADS), 0, st, (u64*)S.keys.p,
                                (const u32*)S.off.p, (const uint4*)S.chunkdesc.p, S.nchunks, g.b, (u32*)S.ovf.p,
-                               (uint2*)((char*)S.ovf.p + 16), c->dbg);
+                               (uint4*)((char*)S.ovf.p + 16), c->dbg);
         }
     }
     G.sorted = true;      // enqueued; oversized buckets (if any) are resolved by finalize()
@@ -1674,26 +1740,55 @@ static int finalize(kr_ctx* c, const std::vector<Genome*>& gs) {
         S.count = total[i];
         if (novf[i]) {
             StageScope sc(c, KR_ST_FALLBACK);
-            std::vector<uint2> segs;
-            uint2* dsegs = (uint2*)((char*)S.ovf.p + 16);
+            const u32 nb = 1u << c->g.b;
+            std::vector<uint4> segs;
+            uint4* dsegs = (uint4*)((char*)S.ovf.p + 16);
             if (novf[i] > OVF_MAX) {
-                segs.push_back(make_uint2(0, total[i]));
-                HIPCHK(c, hipMemcpy(dsegs, segs.data(), 8, hipMemcpyHostToDevice));
+                segs.push_back(make_uint4(0, total[i], 0, nb));      // everything: bucket range [0, nb)
             } else {
                 segs.resize(novf[i]);
-                HIPCHK(c, hipMemcpy(segs.data(), dsegs, (size_t)novf[i] * 8, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(segs.data(), dsegs, (size_t)novf[i] * 16, hipMemcpyDeviceToHost));
+                for (auto& sg : segs) sg.w = sg.z + 1;               // bucket range [f, f + 1)
             }
-            u32 maxlen = 0;
-            for (auto& sg : segs) maxlen = std::max(maxlen, sg.y - sg.x);
             c->overflow_segments += (int64_t)segs.size();
-            dim3 grid(std::min<u32>((maxlen + 255) / 256, 65535), (u32)segs.size());
-            for (u64 kk = 2; kk < 2ull * maxlen; kk <<= 1) {
-                for (u64 j = kk >> 1; j > 0; j >>= 1) {
-                    hipLaunchKernelGGL(k_bitonic_stage, grid, dim3(256), 0, st, (u64*)S.keys.p,
-                                       (const uint2*)dsegs, (u32)kk, (u32)j, j == (kk >> 1) ? 1 : 0);
-                    c->fallback_launches++;
-                }
+            // (1) sort the 4096-key tiles of every segment with the LDS sorter
+            std::vector<uint4> tiles;
+            u32 maxlen = 0;
+            for (auto& sg : segs) {
+                maxlen = std::max(maxlen, sg.y - sg.x);
+                for (u32 t = sg.x; t < sg.y; t += LS_CAP) tiles.push_back(make_uint4(t, std::min(t + LS_CAP, sg.y), sg.z, sg.w));
             }
+            int rc;
+            if ((rc = ensure(c, c->fbdesc, tiles.size() * 16 + 16))) return rc;
+            if ((rc = ensure(c, c->fbsegs, (segs.size() + 1) * 16))) return rc;
+            HIPCHK(c, hipMemcpy(c->fbdesc.p, tiles.data(), tiles.size() * 16, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemsetAsync(S.ovf.p, 0, 16, st));
+            hipLaunchKernelGGL(k_localsort, dim3(std::min<u32>((u32)tiles.size(), (u32)c->ls_grid)), dim3(LS_THREADS), 0,
+                               st, (u64*)S.keys.p, (const u32*)S.off.p, (const uint4*)c->fbdesc.p, (u32)tiles.size(),
+                               c->g.b, (u32*)S.ovf.p, dsegs, c->dbg);
+            c->fallback_launches++;
+            // (2) merge rounds: runs of `run` keys -> 2 * run, through the lane scratch and back
+            Lane& ln = c->lanes[0];
+            if ((rc = ensure(c, ln.tmpkeys, ((size_t)total[i] + 2) * 8))) return rc;
+            for (u64 run = LS_CAP; run < maxlen; run *= 2) {
+                std::vector<uint4> act;
+                u32 ntiles = 0;
+                for (auto& sg : segs) {
+                    u32 len = sg.y - sg.x;
+                    if (len <= run) continue;
+                    act.push_back(make_uint4(sg.x, sg.y, ntiles, 0));
+                    ntiles += (len + MG_TILE - 1) / MG_TILE;
+                }
+                if (act.empty()) break;
+                HIPCHK(c, hipMemcpy(c->fbsegs.p, act.data(), act.size() * 16, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_seg_merge, dim3(ntiles), dim3(MG_T), 0, st, (const u64*)S.keys.p,
+                                   (u64*)ln.tmpkeys.p, (const uint4*)c->fbsegs.p, (u32)act.size(), (u32)run);
+                hipLaunchKernelGGL(k_seg_copy, dim3(ntiles), dim3(256), 0, st, (const u64*)ln.tmpkeys.p,
+                                   (u64*)S.keys.p, (const uint4*)c->fbsegs.p, (u32)act.size());
+                HIPCHK(c, hipStreamSynchronize(st));      // fbsegs is rewritten next round
+                c->fallback_launches += 2;
+            }
+            HIPCHK(c, hipGetLastError());
         }
     }
     for (Genome* G : tg) {
