@@ -51,25 +51,56 @@ __device__ __forceinline__ bool slice_key(u64& key, const Geom& g) {
     return true;
 }
 
-#define NWG 1024           // persistent workgroups of the histogram / pass-1 kernels (4 per CU)
+// tuning constants (overridable with -D for A/B builds)
+#ifndef NWG
+#define NWG 2048           // persistent workgroups of the histogram / pass-1 kernels (A/B: 2048 beats 1024 by ~7 % on k_scatter1)
+#endif
+#ifndef P1_T
 #define P1_T 256           // threads of those workgroups
-#define P1_WORDS 64         // code words per pass-1 tile (2048 positions, <= 4096 keys)
-#define P1_KPT 16          // keys per thread per tile: 8 positions x 2 strands
+#endif
+#ifndef P1_WORDS
+#define P1_WORDS 64        // code words per pass-1 tile (2048 positions, <= 4096 keys)
+#endif
+#define P1_TPW (P1_T / P1_WORDS)        // threads per code word
+#define P1_PPT (32 / P1_TPW)            // window positions per thread
+#define P1_KPT (2 * P1_PPT)             // keys per thread per tile: positions x 2 strands
 #define P1_STAGE (P1_WORDS * 64)
-#define P2_TILE 4096u      // keys per pass-2 tile
+#ifndef P2_TILE
+#define P2_TILE 8192u      // keys per pass-2 tile (A/B: 8192 beats 4096 by ~20 % on k_scatter2: half the barriers per key, 256-byte runs)
+#endif
+#ifndef P2_T
 #define P2_T 512           // threads of a pass-2 workgroup
+#endif
 #define P2_KPT (P2_TILE / P2_T)
+#ifndef LS_T
 #define LS_T 2048u         // local-sort chunk window (keys)
+#endif
+#ifndef LS_CAP
 #define LS_CAP 4096u       // local-sort capacity (keys in LDS)
+#endif
+#ifndef LS_THREADS
 #define LS_THREADS 512
+#endif
 #define LS_PER (LS_CAP / LS_THREADS)
-#define LS_WPT (LS_NB / 2 / LS_THREADS)   // packed counter words per thread in the scan
+#ifndef LS_NB
 #define LS_NB 4096u        // sub-bins of the LDS bucket sort
+#endif
+#define LS_WPT (LS_NB / 2 / LS_THREADS)   // packed counter words per thread in the scan
+#define LS_NB_LOG (LS_NB == 4096u ? 12 : (LS_NB == 2048u ? 11 : 13))
 #define LS_BIN_LIMIT 48u   // a fuller sub-bin switches the chunk to the bitonic network
+#ifndef BUCKET_AVG
+#define BUCKET_AVG 1600ull // fan-out policy: largest average fine bucket (the limit is LS_CAP - LS_T)
+#endif
 #define OVF_MAX 4096       // oversized-bucket list capacity
+#ifndef IS_SUB
 #define IS_SUB 2048u       // anchor sub-tile of the intersect kernel
+#endif
+#ifndef IS_THREADS
 #define IS_THREADS 512
+#endif
+#ifndef IS_NB
 #define IS_NB 4096u        // sub-bins over the sub-tile's prefix span
+#endif
 
 __device__ __forceinline__ u64 layout_key(u64 w, const Geom& g) {
     return (w & g.mL) | ((w << g.sR) & g.mR) | ((w >> g.sD) & g.mD);
@@ -332,23 +363,23 @@ __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes
     __shared__ u32 delta[256];
     __shared__ u32 waves[17];
     const u32 tid = threadIdx.x;
-    cur[tid] = base1[tid] + rowoff[(u64)blockIdx.x * 256 + tid];
+    if (tid < 256) cur[tid] = base1[tid] + rowoff[(u64)blockIdx.x * 256 + tid];
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
     for (u64 wt = w0; wt < w1; wt += P1_WORDS) {
-        const u64 w = wt + (tid >> 2);
-        const int j0 = (tid & 3) * 8;
+        const u64 w = wt + tid / P1_TPW;
+        const int j0 = (tid % P1_TPW) * P1_PPT;
         u64 key[P1_KPT];
         u32 r[P1_KPT];
         u32 vm = 0;
-        cnt[tid] = 0;
+        if (tid < 256) cnt[tid] = 0;
         if (w < w1) {
             u32 b0 = bad[w], b1 = bad[w + 1];
             if (b0 != 0xFFFFFFFFu) {
                 u64 c0 = codes[w], c1 = codes[w + 1];
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
+                for (int jj = 0; jj < P1_PPT; jj++) {
                     u64 kf, kr;
                     if (window_keys(c0, c1, b0, b1, j0 + jj, g, kf, kr)) {
                         if (slice_key(kf, g)) { key[2 * jj] = kf; vm |= 1u << (2 * jj); }
@@ -362,11 +393,13 @@ __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes
         for (int q = 0; q < P1_KPT; q++)
             if ((vm >> q) & 1) r[q] = atomicAdd(&cnt[(u32)(key[q] >> 56)], 1u);
         __syncthreads();
-        u32 c = cnt[tid], total;
+        u32 c = tid < 256 ? cnt[tid] : 0, total;
         u32 ex = block_excl_scan(c, waves, total);
-        cnt[tid] = ex;
-        delta[tid] = cur[tid] - ex;
-        cur[tid] += c;
+        if (tid < 256) {
+            cnt[tid] = ex;
+            delta[tid] = cur[tid] - ex;
+            cur[tid] += c;
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < P1_KPT; q++)
@@ -382,7 +415,7 @@ __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes
 
 // ----------------------------------------------------------------------------
 // K4  pass 2 = segmented partition of the pass-1 buckets by the next b-8 bits, in
-// tiles of 4096 keys that never straddle a bucket (tp / tiled1 from k_reduce8):
+// tiles of P2_TILE keys that never straddle a bucket (tp / tiledesc from k_reduce8b):
 //   k_hist2    per-tile digit counts (LDS histogram)           -> tilehist[tile][bin]
 //   k_scan2    per bucket: bin totals -> fine offsets off[], per-tile bin bases (in place)
 //   k_scatter2 per tile: rank, scan, stage digit-sorted in LDS, coalesced runs out
@@ -464,7 +497,10 @@ __global__ __launch_bounds__(P2_T) void k_scatter2(const u64* __restrict__ src, 
     __shared__ u32 cnt[1024];
     __shared__ u32 delta[1024];
     __shared__ u32 waves[17];
-    const u32 tile = blockIdx.x;
+    // tiles are walked from the last to the first: k_hist2 has just streamed the same keys in
+    // ascending order, so its tail is what the 256 MiB Infinity Cache still holds; and the
+    // fine buckets written last (low ones) are the ones k_localsort reads first
+    const u32 tile = gridDim.x - 1 - blockIdx.x;
     const uint2 td = tiledesc[tile];
     const u32 s = td.x, e = td.y;
     if (s >= e) return;
@@ -623,7 +659,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
         if (m > 0) {
             const u32 nbk = hi - lo;
             const int clog = nbk <= 1 ? 0 : 32 - __clz((int)(nbk - 1));
-            const int sh = rb + clog - 12;
+            const int sh = rb + clog - LS_NB_LOG;
             const u64 keylo = (u64)lo << rb;
             for (u32 i = tid; i < LS_NB / 2; i += LS_THREADS) cnt[i] = 0;
             if (tid == 0) s_maxbin = 0;
@@ -1510,13 +1546,13 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     // largest fan-out b = 18); larger genomes are sorted in 4^sb slices by the first sb bases of `left`
     const u64 nmax = 2 * (u64)max_bases;
     int sb = 0;
-    while (sb < 4 && (nmax >> (2 * sb)) > (1600ull << 18)) sb++;
+    while (sb < 4 && (nmax >> (2 * sb)) > (BUCKET_AVG << 18)) sb++;
     if (const char* e = getenv("KR_SLICE_BASES")) sb = std::max(0, std::min(4, atoi(e)));
     if (sb > L) {
         if (getenv("KR_SLICE_BASES")) sb = L;
         else return fail(c, KR_ERR_PARAM, "a genome of %zu bases needs %d slice bases but conserved-left is %d", max_bases, sb, L);
     }
-    if ((nmax >> (2 * sb)) > (1600ull << 18) * 4)
+    if ((nmax >> (2 * sb)) > (BUCKET_AVG << 18) * 4)
         return fail(c, KR_ERR_PARAM, "genome of %zu bases is too large for %d slice bases", max_bases, sb);
     c->sb = sb;
     c->nslices = 1 << (2 * sb);
@@ -1527,7 +1563,7 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     // fan-out: average fine bucket of ~1600 keys or fewer (limit LS_CAP - LS_T = 2048), 8 <= b <= 18
     const u64 per_slice = nmax >> (2 * sb);
     int b = 8;
-    while (b < 18 && (per_slice >> b) > 1600) b++;
+    while (b < 18 && (per_slice >> b) > BUCKET_AVG) b++;
     g.b = b;
     g.rb = 64 - b;
     c->g = g;
