@@ -82,3 +82,54 @@ def prefix_mask(L, R):
     if bits == 0:
         return np.uint64(0)
     return np.uint64((~0 << (64 - bits)) & 0xFFFFFFFFFFFFFFFF)
+
+
+# ----------------------------------------------------------------------------
+# k-mers holding IUPAC ambiguity letters (kept by the reference, kstream.py:11-18) live on
+# the host as strings; these helpers place them among the packed keys in file order
+# ----------------------------------------------------------------------------
+def split_window(w, L, D, R):
+    """window string (left|diag|right as read from the genome) -> (left, diag, right)."""
+    return w[:L], w[L:L + D], w[L + D:L + D + R]
+
+
+def insertion_index(keys, left, diag, right):
+    """Number of packed keys that sort before the k-mer (left, diag, right) in the reference's
+    file order (left, right, diag; C-locale byte order, where IUPAC letters interleave with
+    ACGT: A < B < C < D < G < H < K < M < R < S < T < V < W < Y)."""
+    s = left + right + diag
+    j = next(i for i, ch in enumerate(s) if ch not in "ACGT")
+    prefix = 0
+    for i in range(j):
+        prefix |= "ACGT".index(s[i]) << (62 - 2 * i)
+    c = sum(1 for b in "ACGT" if b < s[j].upper().replace("U", "T"))
+    if s[j] in "Uu":                      # RNA text never reaches here: keys are DNA until output
+        c = 3
+    bound = prefix + (c << (62 - 2 * j))   # c == 4 carries into the prefix: everything under it is smaller
+    if bound >= 1 << 64:
+        return len(keys)
+    return int(np.searchsorted(keys, np.uint64(bound), side="left"))
+
+
+def merged_line_blocks(keys, specials, L, D, R, rna=False, chunk=1 << 22):
+    """Yield the sorted k-mer file as byte blocks: packed keys decoded to text with the
+    IUPAC k-mers (list of (left, diag, right) strings) spliced in at their places."""
+    sp = sorted(specials, key=lambda t: (t[0], t[2], t[1]))
+    cuts = [(insertion_index(keys, *t), t) for t in sp]
+    pos = 0
+    ci = 0
+    n = len(keys)
+    while pos < n or ci < len(cuts):
+        end = min(n, pos + chunk)
+        if ci < len(cuts):
+            end = min(end, cuts[ci][0])
+        if end > pos:
+            yield keys_to_lines_bytes(keys[pos:end], L, D, R, rna)
+            pos = end
+        while ci < len(cuts) and cuts[ci][0] <= pos:
+            l, d, r = cuts[ci][1]
+            line = f"{l},{d},{r}\n"
+            if rna:
+                line = line.replace("T", "U").replace("t", "u")
+            yield line.encode()
+            ci += 1

@@ -84,48 +84,59 @@ def to_bases(records, rna=False):
     return np.frombuffer(buf, dtype=np.uint8)
 
 
-class IupacWindowsUnsupported(NotImplementedError):
-    """A surviving window holds an IUPAC ambiguity letter.  The reference keeps such
-    k-mers (kstream.py:11-18); the 2-bit device path cannot represent them yet."""
+# kstream.py:11-18 COMP_MAP as a translation table (IUPAC letters complement to IUPAC letters)
+_COMP_TABLE = str.maketrans("ATatGCgcRYryMKmkSWswBVbvDHdhNn", "TAtaCGcgYRyrKMkmSWswVBvbHDhdNn")
 
 
-def check_special(bases, k, omit_soft):
-    """Resolve what the device cannot: characters outside ACGTN/acgtn.
+def scan_special(bases, k, omit_soft):
+    """Everything the 2-bit device alphabet cannot carry, resolved exactly on the host.
 
-    Raises KeyError(char) exactly when the reference's _get_complement would
-    (kstream.py:658: a window that survives the soft-mask step holds a character
-    outside COMP_MAP), IupacWindowsUnsupported when a surviving N-free window
-    holds an IUPAC letter.  Cheap when the genome is plain (one vectorised pass).
+    The device handles A/C/G/T (either case) and drops windows holding N, lower case
+    under --omit-soft, or anything else.  The reference differs for two rare kinds of
+    character: (1) a character outside COMP_MAP makes _get_complement raise KeyError
+    (kstream.py:658) for every window that survives the soft-mask step -- raised here,
+    identically; (2) IUPAC ambiguity letters are KEPT (kstream.py:11-18): a surviving,
+    N-free window holding one yields two k-mers (itself and its reverse complement with
+    the letters complemented).  Those k-mers are returned (strings, after the soft-mask
+    mapping) and join the device results in krisp_fasta / kstream.
+    One vectorised pass when the genome is plain; Python only around special characters.
     """
     special = np.flatnonzero(~_PLAIN[bases])
     if len(special) == 0:
-        return
+        return []
     text = bases.tobytes().decode("latin-1")
     seps = np.flatnonzero(bases == 10)
-    iupac_hit = None
-    done_until = -1
+    starts = set()
     for p in special:
         p = int(p)
         i = int(np.searchsorted(seps, p))
         rec_lo = int(seps[i - 1]) + 1 if i > 0 else 0
         rec_hi = int(seps[i]) if i < len(seps) else len(text)
-        lo = max(rec_lo, p - k + 1, done_until + 1 - 0)
-        hi = min(p, rec_hi - k)
-        for s in range(max(rec_lo, p - k + 1), hi + 1):
-            w = text[s:s + k]
-            if omit_soft:
-                if not w.isupper():
-                    continue
-            else:
-                w = w.upper()
-            for ch in reversed(w):
-                if ch not in COMP_KEYS:
-                    raise KeyError(ch)
-            if "N" in w or "n" in w:
+        for s in range(max(rec_lo, p - k + 1), min(p, rec_hi - k) + 1):
+            starts.add(s)
+    out = []
+    for s in sorted(starts):                     # stream order, so the first KeyError is the reference's
+        w = text[s:s + k]
+        if omit_soft:
+            if not w.isupper():
                 continue
-            if iupac_hit is None and any(ch in _IUPAC for ch in w):
-                iupac_hit = (s, w)
-    if iupac_hit is not None:
-        raise IupacWindowsUnsupported(
-            f"window {iupac_hit[1]!r} at offset {iupac_hit[0]} holds an IUPAC ambiguity letter; "
-            "the reference keeps such k-mers, the 2-bit device path does not support them yet")
+        else:
+            w = w.upper()
+        for ch in reversed(w):
+            if ch not in COMP_KEYS:
+                raise KeyError(ch)
+        if "N" in w or "n" in w:
+            continue
+        if any(ch in _IUPAC for ch in w):
+            out.append(w)
+            out.append(w[::-1].translate(_COMP_TABLE))
+    return out
+
+
+class IupacWindowsUnsupported(NotImplementedError):
+    """Raised where k-mers holding IUPAC ambiguity letters cannot be carried (packed files)."""
+
+
+def check_special(bases, k, omit_soft):
+    """KeyError exactly as the reference raises it; returns the IUPAC k-mers (see scan_special)."""
+    return scan_special(bases, k, omit_soft)

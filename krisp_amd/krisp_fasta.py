@@ -67,6 +67,80 @@ def _check_geometry(L, D, R):
 
 
 # ----------------------------------------------------------------------------
+# groups touched by k-mers that hold IUPAC ambiguity letters
+# ----------------------------------------------------------------------------
+_ACGT = frozenset("ACGT")
+
+
+def _pure(s):
+    return _ACGT.issuperset(s)
+
+
+def _prefix_key(left, right):
+    key = 0
+    for i, ch in enumerate(left + right):
+        key |= "ACGT".index(ch) << (62 - 2 * i)
+    return key
+
+
+def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter):
+    """The reference keeps k-mers with IUPAC letters (kstream.py:11-18); the device cannot pack
+    them, so they arrive here as strings: specials[g] = [(left, diag, right), ...] of genome g.
+    Every (left,right) group they touch is rebuilt exactly: its ACGT members are looked up on
+    the device (kr_cands_load + kr_collect), the IUPAC members added, then the reference's
+    rules applied -- present in every genome (intersectAmplicons.py:232-310), ingroup-unique
+    column (Amplicon.py:495-521).  Rare by nature; everything else stays on the device.
+    Returns (set of touched (left,right), list of surviving groups)."""
+    from . import _native
+    L, D, R = geo
+    touched = {(l, r) for sp in specials for (l, d, r) in sp}
+    if not touched:
+        return touched, []
+    members = {}            # (left,right) -> {(left,diag,right) -> {genome index -> count}}
+    pure = sorted({_prefix_key(l, r) for (l, r) in touched if _pure(l) and _pure(r)})
+    if pure:
+        cands = np.zeros(len(pure), dtype=_native.CAND)
+        cands["prefix"] = np.array(pure, dtype=np.uint64)
+        eng.load_cands(cands)
+        recs = eng.collect(ids)
+        for rec in recs:
+            l, d, r = codec.key_columns(rec["key"], L, D, R)
+            gi = ids.index(int(rec["genome"]))
+            members.setdefault((l, r), {}).setdefault((l, d, r), {})
+            m = members[(l, r)][(l, d, r)]
+            m[gi] = m.get(gi, 0) + int(rec["count"])
+    for gi, sp in enumerate(specials):
+        for (l, d, r) in sp:
+            m = members.setdefault((l, r), {}).setdefault((l, d, r), {})
+            m[gi] = m.get(gi, 0) + 1
+    groups = []
+    for P in sorted(members):
+        seqs = members[P]
+        present = set()
+        for m in seqs.values():
+            present.update(m)
+        if len(present) != len(ids):
+            continue
+        group = []
+        for seq in sorted(seqs, key=lambda t: t[1]):
+            labs = []
+            for gi, cnt in seqs[seq].items():
+                labs += [labels[gi]] * cnt
+            group.append(amplicon.Amplicon(seq[0], seq[1], seq[2], labs))
+        if do_filter and not amplicon.ingroup_unique_columns(group, ingroup):
+            continue
+        groups.append(group)
+    return touched, groups
+
+
+def _merge_groups(device_groups, touched, special_groups):
+    """device groups minus the ones re-evaluated on the host, plus those; (left,right) byte order"""
+    out = [g for g in device_groups if (g[0].left, g[0].right) not in touched] + special_groups
+    out.sort(key=lambda g: (g[0].left, g[0].right))
+    return out
+
+
+# ----------------------------------------------------------------------------
 # the fused device flow used by main()
 # ----------------------------------------------------------------------------
 def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,
@@ -88,13 +162,13 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     do_filter = k > L + R
     quirk_all_fail = do_filter and De == 0
     t0 = time.time()
-    texts, rna_any = [], False
+    texts, specials, rna_any = [], [], False
     for f in files:
         records = fasta.read_records(f)
         rna = bool(fasta.detect_rna(records))
         rna_any = rna_any or rna
         bases = fasta.to_bases(records, rna)
-        fasta.check_special(bases, k, omit_soft)
+        specials.append([codec.split_window(w, Le, De, Re) for w in fasta.scan_special(bases, k, omit_soft)])
         texts.append(bases)
     if len(files) == 1:
         # mergeFiles moves the lone k-mer file; its lines carry no label, so later stages
@@ -119,10 +193,17 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             for f, c in zip(files, counts):
                 print(f"=> Extracted and sorted {c:,} {k}-kmers from {f}", file=sys.stderr)
         records = eng.collect(ids) if (ncand and not quirk_all_fail) else np.empty(0, dtype=_native.RECORD)
-    stats.update(device_s=time.time() - t1, kmers=int(sum(counts)), candidates=int(ncand))
+        touched, sgroups = set(), []
+        if any(specials) and not quirk_all_fail:
+            touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels,
+                                               do_filter)
+    stats.update(device_s=time.time() - t1, kmers=int(sum(counts)) + sum(len(sp) for sp in specials),
+                 candidates=int(ncand))
     if quirk_all_fail:
         return [], stats
     groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
+    if touched:
+        groups = _merge_groups(groups, touched, sgroups)
     return groups, stats
 
 
@@ -198,8 +279,15 @@ def mergeFiles(files, output, parallel=1, workdir=None, verbose=True, device=0):
     L, D, R = geo
     _check_geometry(L, D, R)
     labels = [simplename(f) for f in files]
-    keysets = []
+    keysets, specials = [], []
     for lines in contents:
+        flat = b"".join(lines)
+        if flat.translate(None, b"ACGT,"):       # some line holds an IUPAC letter: split them off
+            sp = [ln for ln in lines if ln.translate(None, b"ACGT,")]
+            lines = [ln for ln in lines if not ln.translate(None, b"ACGT,")]
+            specials.append([tuple(x.decode() for x in ln.split(b",")) for ln in sp])
+        else:
+            specials.append([])
         keys = codec.lines_to_keys(lines, L, D, R)
         if len(keys) > 1 and not np.all(keys[1:] >= keys[:-1]):
             raise ValueError("k-mer file is not sorted by (left, right, diag)")
@@ -211,7 +299,12 @@ def mergeFiles(files, output, parallel=1, workdir=None, verbose=True, device=0):
         ids = list(range(len(files)))
         ncand = eng.intersect(ids, [True] * len(ids), apply_filter=False)
         records = eng.collect(ids) if ncand else np.empty(0, dtype=_native.RECORD)
+        touched, sgroups = set(), []
+        if any(specials):
+            touched, sgroups = _special_groups(eng, ids, labels, specials, (L, D, R), frozenset(), False)
     groups = amplicon.groups_from_records(records, labels, L, D, R)
+    if touched:
+        groups = _merge_groups(groups, touched, sgroups)
     with open(output, "w") as f:
         for ln in amplicon.merged_lines(groups):
             f.write(ln + "\n")
@@ -270,27 +363,34 @@ def filterAlignments(kmerfile, output, ingroup, device=0):
         else:
             if D > 16:
                 raise UnsupportedGeometry(f"diagnostic length {D} > 16 exceeds the device mask format")
-            cands = np.zeros(len(groups), dtype=_native.CAND)
+            rows, host_keep = [], []
             for gi, g in enumerate(groups):
+                if not all(_pure(a.diag) for a in g):
+                    # IUPAC letters in a diagnostic column: base sets are sets of letters
+                    # (Amplicon.py:514-520); rare, evaluated here
+                    if amplicon.ingroup_unique_columns(g, ingroup):
+                        host_keep.append(gi)
+                    continue
                 im = om = 0
                 for a in g:
                     m = 0
                     for c, ch in enumerate(a.diag):
-                        if ch not in _BASE_BIT:
-                            raise fasta.IupacWindowsUnsupported(
-                                f"diagnostic sequence {a.diag!r} holds a non-ACGT letter")
                         m |= 1 << (4 * c + _BASE_BIT[ch])
                     for lab in set(a.labels):
                         if lab in ingroup:
                             im |= m
                         else:
                             om |= m
-                cands[gi] = (gi, im, om)            # prefix = group index: sorted, unique
-            with _native.Engine(device=device) as eng:
-                eng.set_params(1, D, 0, max_bases=64)
-                eng.load_cands(cands)
-                eng.merge_cands(None, apply_filter=True)
-                keep = [int(p) for p in eng.cands()["prefix"]]
+                rows.append((gi, im, om))           # prefix = group index: sorted, unique
+            keep = []
+            if rows:
+                cands = np.array(rows, dtype=_native.CAND)
+                with _native.Engine(device=device) as eng:
+                    eng.set_params(1, D, 0, max_bases=64)
+                    eng.load_cands(cands)
+                    eng.merge_cands(None, apply_filter=True)
+                    keep = [int(p) for p in eng.cands()["prefix"]]
+            keep = sorted(keep + host_keep)
     with open(output, "w") as f:
         for gi in keep:
             for a in groups[gi]:

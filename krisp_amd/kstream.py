@@ -89,12 +89,13 @@ class kstream:
         records = fasta.read_records(sequences)
         rna = bool(fasta.detect_rna(records))
         bases = fasta.to_bases(records, rna)
-        fasta.check_special(bases, L + D + R, self.omitsoft)
+        special = [codec.split_window(w, L, D, R)
+                   for w in fasta.scan_special(bases, L + D + R, self.omitsoft)]
         with _native.Engine(device=self.device) as eng:
             eng.set_params(L, D, R, omit_soft=self.omitsoft, max_bases=len(bases))
             eng.add(0, bases)
             keys = eng.keys(0).copy()
-        return keys, rna
+        return keys, rna, special
 
     # ------------------------------------------------------------------ host chain
     def _host_stream(self, sequences):
@@ -173,9 +174,8 @@ class kstream:
     def __call__(self, sequences):
         geo = self.device_geometry()
         if geo is not None:
-            keys, rna = self._device_keys(sequences, geo)
-            for s in range(0, len(keys), _WRITE_CHUNK):
-                blob = codec.keys_to_lines_bytes(keys[s:s + _WRITE_CHUNK], *geo, rna=rna)
+            keys, rna, special = self._device_keys(sequences, geo)
+            for blob in codec.merged_line_blocks(keys, special, *geo, rna=rna, chunk=_WRITE_CHUNK):
                 yield from blob.decode("ascii").split("\n")[:-1]
             return
         seqs, rna = self._host_stream(sequences)
@@ -194,11 +194,11 @@ class kstream:
             sequences = self.sequences
         geo = self.device_geometry()
         if geo is not None:
-            keys, rna = self._device_keys(sequences, geo)
+            keys, rna, special = self._device_keys(sequences, geo)
             with open(filename, "wb") as f:
-                for s in range(0, len(keys), _WRITE_CHUNK):
-                    f.write(codec.keys_to_lines_bytes(keys[s:s + _WRITE_CHUNK], *geo, rna=rna))
-            return int(len(keys))
+                for blob in codec.merged_line_blocks(keys, special, *geo, rna=rna, chunk=_WRITE_CHUNK):
+                    f.write(blob)
+            return int(len(keys)) + len(special)
         seqs, rna = self._host_stream(sequences)
         if rna:
             seqs = (s.replace("T", "U").replace("t", "u") for s in seqs)

@@ -158,9 +158,9 @@ def test_check_special_semantics():
     with pytest.raises(KeyError):
         fasta.check_special(b("ACG-AC"), 4, True)                     # isupper() ignores '-'
     fasta.check_special(b("ACX\nGTAC"), 4, False)                     # no window spans the separator
-    with pytest.raises(fasta.IupacWindowsUnsupported):
-        fasta.check_special(b("ACGTRACGT"), 4, False)
-    fasta.check_special(b("ACNRNAC"), 3, False)                       # every R window also holds N
+    got = fasta.check_special(b("ACGTRACGT"), 4, False)               # IUPAC k-mers are kept, both strands
+    assert sorted(got) == sorted(["CGTR", "YACG", "GTRA", "TYAC", "TRAC", "GTYA", "RACG", "CGTY"])
+    assert fasta.check_special(b("ACNRNAC"), 3, False) == []          # every R window also holds N
 
 
 def test_deduce_geometry_matches_reference_rules():
