@@ -118,6 +118,17 @@ int64_t kr_cands_merge(kr_ctx*, const kr_cand* other, size_t n, int have_other, 
 int64_t kr_collect(kr_ctx*, const int* genome_ids, int n);
 int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
 
+/* Host-side ingest (no GPU involved): the text of a FASTA / sequence-per-line file -> the
+ * upload buffer of kr_genome_upload, with the reference reader's semantics
+ * (kstream/kstream.py:458-479 file lines, 510-537 FASTA iff the first line holds '>', 450 that line is
+ * consumed when one_shot, 556-583 strip + concatenate between headers, 481-508 + 599 RNA detection and
+ * U->T mapping).  universal_newlines != 0 splits on \n, \r, \r\n (plain files), else on \n
+ * (gz / bz2 streams).  out needs n + 1 bytes.  stats[4] = records, characters outside
+ * ACGTNacgtn (the host resolves those), is_rna (-1 undecided, 0, 1), is_fasta.  Returns the
+ * number of bytes written. */
+int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines, int one_shot, uint8_t* out,
+                          size_t cap, int64_t* stats);
+
 int     kr_sync(kr_ctx*);
 /* HIP-event timers on the context's stream */
 int     kr_timer_begin(kr_ctx*);

@@ -47,6 +47,7 @@ SYMBOLS = [
     ("kr_cands_merge", _c.c_int64, [_P, _P, _c.c_size_t, _c.c_int, _c.c_int]),
     ("kr_collect", _c.c_int64, [_P, _P, _c.c_int]),
     ("kr_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
+    ("kr_fasta_to_bases", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     ("kr_sync", _c.c_int, [_P]),
     ("kr_timer_begin", _c.c_int, [_P]),
     ("kr_timer_end_ms", _c.c_double, [_P]),
@@ -87,6 +88,20 @@ def load():
 
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def fasta_to_bases(data, universal_newlines, one_shot=True):
+    """bytes of a FASTA / sequence file -> (uint8 upload buffer, records, special chars, rna, fasta)
+    through the library's one-pass host parser (GIL released: callers may use threads)."""
+    lib = load()
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(len(src) + 1, dtype=np.uint8)
+    stats = np.zeros(4, dtype=np.int64)
+    n = lib.kr_fasta_to_bases(_ptr(src) if len(src) else None, len(src), 1 if universal_newlines else 0,
+                              1 if one_shot else 0, _ptr(out), len(out), _ptr(stats))
+    if n < 0:
+        raise KrispHipError(f"kr_fasta_to_bases: [{n}]")
+    return out[:n], int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
 
 
 class Engine:

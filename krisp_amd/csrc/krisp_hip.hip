@@ -2209,6 +2209,88 @@ int64_t kr_debug_fetch(kr_ctx* c, int id, int what, void* out, size_t cap_bytes)
     return (int64_t)n;
 }
 
+// ----------------------------------------------------------------------------
+// host side: FASTA / sequence text -> upload buffer, one pass, reference reader semantics
+// (kstream.py:458-583; see include/krisp_hip.h).  Pure CPU code; ctypes releases the GIL, so
+// the Python layer ingests several files concurrently.
+// ----------------------------------------------------------------------------
+static inline bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines, int one_shot, uint8_t* out,
+                          size_t cap, int64_t* stats) {
+    if (!text && n) return KR_ERR_PARAM;
+    if (cap < n + 1) return KR_ERR_CAPACITY;
+    size_t pos = 0, o = 0;
+    int64_t nrec = 0;
+    bool first_line = true, fasta = false, in_record = false, any_record = false;
+    auto emit_separator = [&]() {
+        if (any_record) out[o++] = '\n';
+        any_record = true;
+        nrec++;
+    };
+    while (pos < n) {
+        // one line: [pos, eol)
+        size_t eol = pos;
+        if (universal_newlines) { while (eol < n && text[eol] != '\n' && text[eol] != '\r') eol++; }
+        else { while (eol < n && text[eol] != '\n') eol++; }
+        size_t next = eol;
+        if (next < n) {
+            if (universal_newlines && text[next] == '\r' && next + 1 < n && text[next + 1] == '\n') next += 2;
+            else next += 1;
+        }
+        const uint8_t* ln = text + pos;
+        size_t len = eol - pos;
+        pos = next;
+        if (first_line) {
+            first_line = false;
+            fasta = memchr(ln, '>', len) != nullptr;         // decided on the first line only
+            if (one_shot) continue;                          // ... which the detection consumed
+        }
+        while (len && is_space(ln[0])) { ln++; len--; }
+        while (len && is_space(ln[len - 1])) len--;
+        if (!fasta) {                                        // every stripped line is a record
+            emit_separator();
+            memcpy(out + o, ln, len);
+            o += len;
+            continue;
+        }
+        if (len && ln[0] == '>') { in_record = false; continue; }
+        if (!len) continue;
+        if (!in_record) { emit_separator(); in_record = true; }
+        memcpy(out + o, ln, len);
+        o += len;
+    }
+    // RNA iff the first record holding T/t/U/u holds U/u and no T/t (kstream.py:481-508)
+    int rna = -1;
+    for (size_t i = 0, rs = 0; i <= o && rna < 0; i++) {
+        if (i == o || out[i] == '\n') {
+            bool t = false, u = false;
+            for (size_t j = rs; j < i; j++) {
+                uint8_t c = out[j];
+                t |= (c == 'T' || c == 't');
+                u |= (c == 'U' || c == 'u');
+            }
+            if (t) rna = 0; else if (u) rna = 1;
+            rs = i + 1;
+        }
+    }
+    int64_t special = 0;
+    for (size_t i = 0; i < o; i++) {
+        uint8_t c = out[i];
+        if (rna == 1) {
+            if (c == 'U') c = out[i] = 'T';
+            else if (c == 'u') c = out[i] = 't';
+        }
+        switch (c) {
+        case 'A': case 'C': case 'G': case 'T': case 'N': case 'a': case 'c': case 'g': case 't': case 'n':
+        case '\n': break;
+        default: special++;
+        }
+    }
+    if (stats) { stats[0] = nrec; stats[1] = special; stats[2] = rna; stats[3] = fasta ? 1 : 0; }
+    return (int64_t)o;
+}
+
 int64_t kr_debug_inversions(kr_ctx* c, int id) {
     if (!c) return KR_ERR_PARAM;
     auto it = c->genomes.find(id);

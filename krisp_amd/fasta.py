@@ -28,12 +28,12 @@ for _ch in b"ACGTNacgtn\n":
 
 def _read_raw_lines(filename):
     ext = os.path.splitext(filename)[1]
-    if ext == ".gz":
-        with gzip.open(filename, "rb") as f:
-            return f.read().split(b"\n")
-    if ext == ".bz2":
-        with bz2.open(filename, "rb") as f:
-            return f.read().split(b"\n")
+    if ext in (".gz", ".bz2"):
+        with (gzip.open if ext == ".gz" else bz2.open)(filename, "rb") as f:
+            lines = f.read().split(b"\n")
+        if lines and lines[-1] == b"":
+            lines.pop()                     # split() artefact after the final newline, not a line
+        return lines
     with open(filename, "rb") as f:
         return f.read().splitlines()       # text mode's universal newlines
 
@@ -42,8 +42,6 @@ def read_records(source):
     """-> list of bytes records, reference semantics (see module docstring)."""
     if isinstance(source, (str, os.PathLike)):
         lines = _read_raw_lines(os.fspath(source))
-        if lines and lines[-1] == b"":
-            lines.pop()                     # split() artefact, not a line
         one_shot = True
     else:
         one_shot = hasattr(source, "__next__")
@@ -65,6 +63,39 @@ def read_records(source):
     if cur:
         recs.append(b"".join(cur))
     return recs
+
+
+def load_bases(filename):
+    """file -> (upload buffer, is_rna, n_special): the same result as
+    to_bases(read_records(filename)) through the library's one-pass host parser."""
+    from . import _native
+    ext = os.path.splitext(filename)[1]
+    if ext == ".gz":
+        with gzip.open(filename, "rb") as f:
+            data, universal = f.read(), False
+    elif ext == ".bz2":
+        with bz2.open(filename, "rb") as f:
+            data, universal = f.read(), False
+    else:
+        with open(filename, "rb") as f:
+            data, universal = f.read(), True
+    bases, _nrec, nspecial, rna, _fasta = _native.fasta_to_bases(data, universal, one_shot=True)
+    return bases, bool(rna), nspecial
+
+
+def ingest(source, k, omit_soft):
+    """file name or iterable of sequence strings -> (upload buffer, is_rna, IUPAC k-mers).
+    Files go through the library's one-pass parser; characters the device cannot carry are
+    resolved here (scan_special) -- skipped entirely when the genome has none."""
+    if isinstance(source, (str, os.PathLike)):
+        bases, rna, nspecial = load_bases(os.fspath(source))
+    else:
+        records = read_records(source)
+        rna = bool(detect_rna(records))
+        bases = to_bases(records, rna)
+        nspecial = 1
+    special = scan_special(bases, k, omit_soft) if nspecial else []
+    return bases, rna, special
 
 
 def detect_rna(records):

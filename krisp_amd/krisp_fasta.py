@@ -162,14 +162,12 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     do_filter = k > L + R
     quirk_all_fail = do_filter and De == 0
     t0 = time.time()
-    texts, specials, rna_any = [], [], False
-    for f in files:
-        records = fasta.read_records(f)
-        rna = bool(fasta.detect_rna(records))
-        rna_any = rna_any or rna
-        bases = fasta.to_bases(records, rna)
-        specials.append([codec.split_window(w, Le, De, Re) for w in fasta.scan_special(bases, k, omit_soft)])
-        texts.append(bases)
+    # ingest: files are read, inflated and parsed concurrently (the parser releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(len(files), os.cpu_count() or 1, 16))) as pool:
+        loaded = list(pool.map(lambda f: fasta.ingest(f, k, omit_soft), files))
+    texts = [b for b, _, _ in loaded]
+    specials = [[codec.split_window(w, Le, De, Re) for w in sp] for _, _, sp in loaded]
     if len(files) == 1:
         # mergeFiles moves the lone k-mer file; its lines carry no label, so later stages
         # label them with the file they read: simplename('merged_file.txt') (shared.py:373)

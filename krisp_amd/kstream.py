@@ -86,11 +86,8 @@ class kstream:
     def _device_keys(self, sequences, geo):
         from . import _native
         L, D, R = geo
-        records = fasta.read_records(sequences)
-        rna = bool(fasta.detect_rna(records))
-        bases = fasta.to_bases(records, rna)
-        special = [codec.split_window(w, L, D, R)
-                   for w in fasta.scan_special(bases, L + D + R, self.omitsoft)]
+        bases, rna, windows = fasta.ingest(sequences, L + D + R, self.omitsoft)
+        special = [codec.split_window(w, L, D, R) for w in windows]
         with _native.Engine(device=self.device) as eng:
             eng.set_params(L, D, R, omit_soft=self.omitsoft, max_bases=len(bases))
             eng.add(0, bases)

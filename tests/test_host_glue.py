@@ -209,3 +209,44 @@ def test_missing_library_fails_loudly(monkeypatch):
         _native.load()
     with pytest.raises(_native.KrispHipError):
         _native.Engine()
+
+
+def test_library_ingest_matches_the_python_reader(tmp_path):
+    """kr_fasta_to_bases (one-pass host parser in the library) == to_bases(read_records(...)),
+    the reader that is itself pinned to the reference (test above): headers, blank and indented
+    lines, CR/LF flavours, gzip, RNA, non-FASTA inputs, first-line consumption."""
+    import random
+
+    def check(path):
+        recs = fasta.read_records(path)
+        rna = bool(fasta.detect_rna(recs))
+        want = fasta.to_bases(recs, rna)
+        got, r, nspecial = fasta.load_bases(path)
+        assert got.tobytes() == want.tobytes(), path
+        assert r == rna
+        assert nspecial == int((~fasta._PLAIN[want]).sum())
+
+    for c in KS:
+        if c["file_text"] is not None:
+            check(_src(c, tmp_path))
+    for fn in os.listdir(os.path.join(GOLDEN, "c1")):
+        check(os.path.join(GOLDEN, "c1", fn))
+    rng = random.Random(5)
+    for i in range(300):
+        pieces = []
+        for _ in range(rng.randint(0, 12)):
+            kind = rng.random()
+            if kind < 0.25:
+                pieces.append(">" + "".join(rng.choice("abc >x") for _ in range(rng.randint(0, 6))))
+            elif kind < 0.35:
+                pieces.append(rng.choice(["", " ", "\t"]))
+            else:
+                pieces.append(rng.choice(["", " ", "  "]) +
+                              "".join(rng.choice("ACGTacgtNnUuRY>x ") for _ in range(rng.randint(0, 30))) +
+                              rng.choice(["", " ", "\t "]))
+        nl = rng.choice(["\n", "\r\n", "\r", "\n"])
+        text = nl.join(pieces) + rng.choice(["", nl, nl + nl])
+        for ext in (".fa", ".txt.gz"):
+            p = str(tmp_path / f"r{i}{ext}")
+            (gzip.open if ext.endswith(".gz") else open)(p, "wb").write(text.encode())
+            check(p)
