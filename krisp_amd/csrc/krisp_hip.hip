@@ -716,11 +716,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
                         u32 b0 = cnt16_get(cnt, sb);
                         u32 b1 = sb + 1 < LS_NB ? cnt16_get(cnt, sb + 1) : m;
                         u32 rank = b0;
-                        if (!(dbg & 8))
-                            for (u32 q = b0; q < b1; q++) {
-                                u64 kq = S[q];
-                                rank += (kq < kk) || (kq == kk && q < p);
-                            }
+                        for (u32 q = b0; q < b1; q++) {
+                            u64 kq = S[q];
+                            rank += (kq < kk) || (kq == kk && q < p);
+                        }
                         keys[s + rank] = kk;
                     }
                 }
@@ -891,13 +890,13 @@ struct IsectArgs {
     kr_cand* tmp;
     u32* chunkcnt;
     int apply_filter;
-    int dbg;   // ablation switches (KR_DBG env): 1 = no probes, 2 = no atomics, 4 = no streaming
+    int dbg;   // KR_DBG env: 32 = always take the generic sub-tile path (tests cover both)
 };
 
 template <bool WIDE>
 __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first, u64 last, int sh,
                                             const u64* heads, const unsigned short* binstart, u32* present,
-                                            u64* inm, u64* outm, const Geom& g, int LR, int dbg = 0) {
+                                            u64* inm, u64* outm, const Geom& g, int LR) {
     u64 pre = key & g.pmask;
     if (pre < first || pre > last) return;
     u32 sb = (u32)((pre - first) >> sh);
@@ -905,7 +904,6 @@ __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first
     const u32 hend = binstart[sb + 1];
     for (; h < hend; h++) {
         if (heads[h] == pre) {
-            if (dbg & 2) { asm volatile("" ::"v"(h)); return; }
             atomicOr(&present[h], 1u << gi);
             if (g.D > 0) {
                 u64 dm = diag_mask(key, LR, g.D);
@@ -1011,7 +1009,7 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
         }
         if (fast && tid < (u32)a.n) {
             u32 s0 = a.off[tid][fcur], e0 = a.off[tid][fend];
-            if ((int)tid == a.anchor || (a.dbg & 4)) e0 = s0;      // the anchor's own keys are in registers
+            if ((int)tid == a.anchor) e0 = s0;                     // the anchor's own keys are in registers
             sstart[tid] = s0;
             send[tid] = e0;
         }
@@ -1043,7 +1041,7 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
                 const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
                 u32 s0 = a.off[tid][fl];
                 sstart[tid] = s0;
-                send[tid] = (a.dbg & 4) ? s0 : a.off[tid][fh];
+                send[tid] = a.off[tid][fh];
             }
             // order-preserving sub-bins over [first, last]: binstart[sb] = #heads with bin < sb
             for (u32 h = tid; h < nheads; h += IS_THREADS) {
@@ -1104,12 +1102,9 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
 #pragma unroll
                     for (int q = 0; q < (int)IS_APT; q++) {
                         u32 i = i0 + q * IS_THREADS + tid;
-                        if (i < e) {
-                            if (a.dbg & 1) asm volatile("" ::"v"(cur[q]));
-                            else
-                                isect_probe<WIDE>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm,
-                                                  outm, g, LR, a.dbg);
-                        }
+                        if (i < e)
+                            isect_probe<WIDE>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm, outm,
+                                              g, LR);
                     }
                 }
 #pragma unroll
@@ -1313,7 +1308,7 @@ struct kr_ctx {
     double stage_ms[KR_ST_COUNT] = {0};
     int64_t stage_n[KR_ST_COUNT] = {0};
     int64_t fallback_launches = 0, overflow_segments = 0;
-    int dbg = 0;   // KR_DBG ablation switches (benchmark diagnostics only)
+    int dbg = 0;   // KR_DBG env (test switch, results unchanged): 32 = generic intersect sub-tile path
 };
 
 static int fail(kr_ctx* c, int code, const char* fmt, ...) {
