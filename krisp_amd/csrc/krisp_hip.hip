@@ -178,15 +178,23 @@ __global__ void k_pack(const uint8_t* __restrict__ bases, u64 n, u64* __restrict
 // ----------------------------------------------------------------------------
 // top key byte of both strands of window j without building the keys (valid when L >= 4:
 // the first four bases of `left` are the first four bases of the strand's window)
-__device__ __forceinline__ bool window_top_bytes(u64 c0, u64 c1, u32 b0, u32 b1, int j, int k, u32& tf, u32& tr) {
+// top 16 key bits of both strands of window j without building the keys (valid when L >= 8:
+// the first eight bases of `left` are the first eight bases of the strand's window)
+__device__ __forceinline__ bool window_top16(u64 c0, u64 c1, u32 b0, u32 b1, int j, int k, u32& tf, u32& tr) {
     u64 x = j ? ((c0 << (2 * j)) | (c1 >> (64 - 2 * j))) : c0;
     u32 bm = j ? ((b0 << j) | (b1 >> (32 - j))) : b0;
     if ((bm >> (32 - k)) != 0) return false;
-    tf = (u32)(x >> 56);
-    u32 t = (u32)(x >> (64 - 2 * k)) & 0xFFu;      // last four bases of the window
-    t = ~t & 0xFFu;                                 // complement
-    t = ((t & 0x03u) << 6) | ((t & 0x0Cu) << 2) | ((t & 0x30u) >> 2) | ((t & 0xC0u) >> 6);   // reverse
-    tr = t;
+    tf = (u32)(x >> 48);
+    u32 t = ~(u32)(x >> (64 - 2 * k)) & 0xFFFFu;   // complement of the last eight bases of the window
+    t = __brev(t) >> 16;                            // reverse the 16 bits ...
+    tr = ((t & 0xAAAAu) >> 1) | ((t & 0x5555u) << 1);   // ... and restore the order inside each base
+    return true;
+}
+
+// the slice test and the pass-1 digit from those 16 bits
+__device__ __forceinline__ bool top16_in_slice(u32 t16, const Geom& g, u32& d1) {
+    if (g.sbits && (t16 >> (16 - g.sbits)) != g.slice) return false;
+    d1 = (t16 >> (8 - g.sbits)) & 0xFFu;
     return true;
 }
 
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
-    const bool cheap = g.L >= 4 && g.sbits == 0;
+    const bool cheap = g.L >= 8;
     for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
@@ -206,10 +214,10 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
         if (cheap) {
 #pragma unroll 8
             for (int j = 0; j < 32; j++) {
-                u32 tf, tr;
-                if (!window_top_bytes(c0, c1, b0, b1, j, g.k, tf, tr)) continue;
-                atomicAdd(&lhist[tf], 1u);
-                atomicAdd(&lhist[tr], 1u);
+                u32 tf, tr, d1;
+                if (!window_top16(c0, c1, b0, b1, j, g.k, tf, tr)) continue;
+                if (top16_in_slice(tf, g, d1)) atomicAdd(&lhist[d1], 1u);
+                if (top16_in_slice(tr, g, d1)) atomicAdd(&lhist[d1], 1u);
             }
         } else {
 #pragma unroll 4
