@@ -901,7 +901,11 @@ struct IsectArgs {
     int dbg;   // KR_DBG env: 32 = always take the generic sub-tile path (tests cover both)
 };
 
-template <bool WIDE>
+// per-head state in LDS, by mask format FMT:
+//   0 compact (D <= 4)  one u64: present << 32 | out << 16 | in     -> one atomic per matching key
+//   1 narrow  (D <= 8)  present u32 + one u64: out << 32 | in
+//   2 wide    (D <= 16) present u32 + in u64 + out u64
+template <int FMT>
 __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first, u64 last, int sh,
                                             const u64* heads, const unsigned short* binstart, u32* present,
                                             u64* inm, u64* outm, const Geom& g, int LR) {
@@ -912,11 +916,15 @@ __device__ __forceinline__ void isect_probe(u64 key, int gi, bool ing, u64 first
     const u32 hend = binstart[sb + 1];
     for (; h < hend; h++) {
         if (heads[h] == pre) {
-            atomicOr(&present[h], 1u << gi);
-            if (g.D > 0) {
-                u64 dm = diag_mask(key, LR, g.D);
-                if (WIDE) atomicOr((u64*)(ing ? &inm[h] : &outm[h]), dm);
-                else atomicOr((u64*)&inm[h], ing ? dm : (dm << 32));   // D <= 8: in | out<<32
+            const u64 dm = g.D > 0 ? diag_mask(key, LR, g.D) : 0;
+            if (FMT == 0) {
+                atomicOr((u64*)&inm[h], ((u64)1 << (32 + gi)) | (ing ? dm : (dm << 16)));
+            } else {
+                atomicOr(&present[h], 1u << gi);
+                if (g.D > 0) {
+                    if (FMT == 2) atomicOr((u64*)(ing ? &inm[h] : &outm[h]), dm);
+                    else atomicOr((u64*)&inm[h], ing ? dm : (dm << 32));
+                }
             }
             return;
         }
@@ -958,13 +966,16 @@ __device__ __forceinline__ u32 compact_flags(const bool (&flag)[IS_APT], u32 (&p
     return mpref[64];
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArgs a, Geom g) {
+template <int FMT>
+__global__ __launch_bounds__(IS_THREADS, FMT == 2 ? 4 : (FMT == 1 ? 6 : 8)) void k_intersect(IsectArgs a, Geom g) {
+    constexpr bool WIDE = FMT == 2;
+    constexpr u32 NBINS = FMT == 0 ? IS_NB / 2 : IS_NB;      // compact: 4 workgroups per CU fit
+    constexpr int NB_LOG = FMT == 0 ? 11 : 12;
     __shared__ __attribute__((aligned(16))) u64 heads[IS_SUB];
     __shared__ __attribute__((aligned(16))) u64 inm[IS_SUB];
     __shared__ __attribute__((aligned(16))) u64 outm[WIDE ? IS_SUB : 1];
-    __shared__ u32 present[IS_SUB];
-    __shared__ unsigned short binstart[IS_NB + 2];
+    __shared__ u32 present[FMT == 0 ? 1 : IS_SUB];
+    __shared__ unsigned short binstart[NBINS + 2];
     __shared__ u64 masks[64];
     __shared__ u32 mpref[65];
     __shared__ u32 sstart[MAXG], send[MAXG];
@@ -1034,16 +1045,20 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
         for (int q = 0; q < (int)IS_APT; q++) {
             if (flag[q]) {
                 heads[pos[q]] = ak[q] & g.pmask;
-                present[pos[q]] = fast ? (1u << a.anchor) : 0u;
-                inm[pos[q]] = 0;
-                if (WIDE) outm[pos[q]] = 0;
+                if (FMT == 0) {
+                    inm[pos[q]] = fast ? ((u64)1 << (32 + a.anchor)) : 0ull;
+                } else {
+                    present[pos[q]] = fast ? (1u << a.anchor) : 0u;
+                    inm[pos[q]] = 0;
+                    if (WIDE) outm[pos[q]] = 0;
+                }
             }
         }
         __syncthreads();
         if (nheads > 0) {
             const u64 first = heads[0], last = heads[nheads - 1];
             const u64 span = last - first;
-            const int sh = span < IS_NB ? 0 : (64 - __clzll((long long)span) - 12);
+            const int sh = span < NBINS ? 0 : (64 - __clzll((long long)span) - NB_LOG);
             if (!fast && tid < (u32)a.n) {
                 const u32 fl = (u32)(first >> g.rb);
                 const u32 fh = (u32)((last | ~g.pmask) >> g.rb) + 1;
@@ -1059,7 +1074,7 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
             }
             {
                 u32 lastbin = (u32)(span >> sh);
-                for (u32 q = lastbin + 1 + tid; q <= IS_NB; q += IS_THREADS) binstart[q] = (unsigned short)nheads;
+                for (u32 q = lastbin + 1 + tid; q <= NBINS; q += IS_THREADS) binstart[q] = (unsigned short)nheads;
             }
             if (fast && g.D > 0) {
                 // the anchor's own diagnostic columns, straight from registers
@@ -1069,8 +1084,9 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
                     if (p < cnt) {
                         u32 h = flag[q] ? pos[q] : pos[q] - 1;
                         u64 dm = diag_mask(ak[q], LR, g.D);
-                        if (WIDE) atomicOr((u64*)(anchor_in ? &inm[h] : &outm[h]), dm);
-                        else atomicOr((u64*)&inm[h], anchor_in ? dm : (dm << 32));
+                        if (FMT == 2) atomicOr((u64*)(anchor_in ? &inm[h] : &outm[h]), dm);
+                        else if (FMT == 1) atomicOr((u64*)&inm[h], anchor_in ? dm : (dm << 32));
+                        else atomicOr((u64*)&inm[h], anchor_in ? dm : (dm << 16));
                     }
                 }
             }
@@ -1111,7 +1127,7 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
                     for (int q = 0; q < (int)IS_APT; q++) {
                         u32 i = i0 + q * IS_THREADS + tid;
                         if (i < e)
-                            isect_probe<WIDE>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm, outm,
+                            isect_probe<FMT>(cur[q], gi, ing, first, last, sh, heads, binstart, present, inm, outm,
                                               g, LR);
                     }
                 }
@@ -1127,9 +1143,10 @@ __global__ __launch_bounds__(IS_THREADS, WIDE ? 4 : 6) void k_intersect(IsectArg
                 flag[q] = false;
                 im[q] = om[q] = 0;
                 if (h < nheads) {
-                    flag[q] = present[h] == full;
-                    im[q] = WIDE ? inm[h] : (inm[h] & 0xFFFFFFFFull);
-                    om[q] = WIDE ? outm[h] : (inm[h] >> 32);
+                    const u64 st = inm[h];
+                    flag[q] = (FMT == 0 ? (u32)(st >> 32) : present[h]) == full;
+                    im[q] = FMT == 2 ? st : (FMT == 1 ? (st & 0xFFFFFFFFull) : (st & 0xFFFFull));
+                    om[q] = FMT == 2 ? outm[h] : (FMT == 1 ? (st >> 32) : ((st >> 16) & 0xFFFFull));
                     if (flag[q] && a.apply_filter && g.D > 0) flag[q] = passes_filter(im[q], om[q], g.D);
                 }
             }
@@ -1317,6 +1334,7 @@ struct kr_ctx {
     int64_t stage_n[KR_ST_COUNT] = {0};
     int64_t fallback_launches = 0, overflow_segments = 0;
     int dbg = 0;   // KR_DBG env (test switch, results unchanged): 32 = generic intersect sub-tile path
+    int isect_fmt = 0;   // KR_ISECT_FMT env (A/B switch): 1 = narrow mask format also for D <= 4
 };
 
 static int fail(kr_ctx* c, int code, const char* fmt, ...) {
@@ -1469,6 +1487,8 @@ kr_ctx* kr_create(int device, size_t hbm_budget_bytes) {
     {
         const char* e = getenv("KR_DBG");
         c->dbg = e ? atoi(e) : 0;
+        const char* e2 = getenv("KR_ISECT_FMT");
+        c->isect_fmt = e2 ? atoi(e2) : 0;
         int ncu = 256, per = 3;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_localsort, LS_THREADS, 0) != hipSuccess || per < 1)
@@ -1993,9 +2013,11 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
         {
             StageScope sc(c, KR_ST_INTERSECT);
             if (g.D > 8)
-                hipLaunchKernelGGL(k_intersect<true>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
+                hipLaunchKernelGGL(k_intersect<2>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
+            else if (g.D > 4 || c->isect_fmt == 1)
+                hipLaunchKernelGGL(k_intersect<1>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
             else
-                hipLaunchKernelGGL(k_intersect<false>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
+                hipLaunchKernelGGL(k_intersect<0>, dim3(AS.nchunks), dim3(IS_THREADS), 0, st, a, g);
         }
         u32 total = 0;
         {
