@@ -14,6 +14,9 @@ LIB_PATH = os.path.join(HERE, "libkrisp_hip.so")
 
 CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
+WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
+WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS = 0, 1, 2, 3
+WIDE_MAX_K = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
@@ -47,6 +50,9 @@ SYMBOLS = [
     ("kr_cands_merge", _c.c_int64, [_P, _P, _c.c_size_t, _c.c_int, _c.c_int]),
     ("kr_collect", _c.c_int64, [_P, _P, _c.c_int]),
     ("kr_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
+    ("kr_set_params_wide", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_size_t]),
+    ("kr_wide_run", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
+    ("kr_wide_fetch", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_fasta_to_bases", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     ("kr_sync", _c.c_int, [_P]),
     ("kr_timer_begin", _c.c_int, [_P]),
@@ -205,6 +211,24 @@ class Engine:
         n = self._check(self.lib.kr_collect(self.ctx, _ptr(ids), len(ids)), "kr_collect")
         out = np.empty(max(n, 1), dtype=RECORD)
         self._check(self.lib.kr_fetch(self.ctx, _ptr(out), n), "kr_fetch")
+        return out[:n]
+
+    # ---- wide windows (k > 32 or D > 16)
+    def set_params_wide(self, L, D, R, omit_soft=False, max_bases=0):
+        self._check(self.lib.kr_set_params_wide(self.ctx, L, D, R, SOFT_OMIT if omit_soft else SOFT_MAP,
+                                                max_bases), "kr_set_params_wide")
+        self.params = (L, D, R)
+
+    def wide_run(self, gids, is_ingroup, apply_filter=True):
+        ids = np.asarray(gids, dtype=np.int32)
+        flags = np.asarray([1 if f else 0 for f in is_ingroup], dtype=np.uint8)
+        return self._check(self.lib.kr_wide_run(self.ctx, _ptr(ids), len(ids), _ptr(flags),
+                                                1 if apply_filter else 0), "kr_wide_run")
+
+    def wide_fetch(self, what):
+        n = self._check(self.lib.kr_wide_fetch(self.ctx, what, None, 0), "kr_wide_fetch")
+        out = np.empty(max(n, 1), dtype=WIDE_HIT if what == WIDE_HITS else np.uint64)
+        self._check(self.lib.kr_wide_fetch(self.ctx, what, _ptr(out), out.nbytes), "kr_wide_fetch")
         return out[:n]
 
     # ---- timing

@@ -41,6 +41,17 @@ struct Geom {
     int rb;         // 64 - b
     int LRrel;      // L - sb + R: bases of the (left,right) prefix of a relative key
     u64 pmask;      // top 2 * LRrel bits of a relative key
+    // --- wide windows (amplicon longer than one key; see the "wide path" section).  The key
+    // generators of k_hist8<1> / k_scatter1<1> read the window from global memory instead:
+    int wmode;      // 1 = sub-window spectrum, 2 = dictionary composite
+    int wk;         // window length: no bad base in [pos, pos + wk)
+    int wfo, wro;   // mode 1: forward key = wlen bases at window offset wfo, reverse key = the
+    int wlen;       //         reverse complement of the wlen bases at window offset wro
+    int wL, wR;     // mode 2: key = rank of `left` in dictL << wshL | rank of `right` in dictR << wshR
+    int wshL, wshR;
+    int wibL, wibR; // index bits of the dictionaries (idx[top ib bits] = lower bound)
+    const u64 *wdictL, *wdictR;
+    const u32 *widxL, *widxR;
 };
 
 // absolute key -> relative key of the current slice; false when the key is not in the slice
@@ -92,6 +103,7 @@ __device__ __forceinline__ bool slice_key(u64& key, const Geom& g) {
 #define BUCKET_AVG 1600ull // fan-out policy: largest average fine bucket (the limit is LS_CAP - LS_T)
 #endif
 #define OVF_MAX 4096       // oversized-bucket list capacity
+#define PAD_WORDS 6         // all-bad code words after a genome (2 for packed windows, 6 for KR_WIDE_MAX_K bases)
 #ifndef IS_SUB
 #define IS_SUB 2048u       // anchor sub-tile of the intersect kernel
 #endif
@@ -120,6 +132,77 @@ __device__ __forceinline__ bool window_keys(u64 c0, u64 c1, u32 b0, u32 b1, int 
     kf = layout_key(wf, g);
     kr = layout_key(wr, g);
     return true;
+}
+
+// ---- wide windows: the window does not fit two registers, read it from the codes array ----
+// 32 bases starting at base position pos, MSB first
+__device__ __forceinline__ u64 read32(const u64* __restrict__ codes, u64 pos) {
+    const u64 w = pos >> 5;
+    const int j = (int)(pos & 31);
+    const u64 c0 = codes[w];
+    return j ? ((c0 << (2 * j)) | (codes[w + 1] >> (64 - 2 * j))) : c0;
+}
+// reverse complement of all 32 bases of x
+__device__ __forceinline__ u64 revcomp32(u64 x) {
+    u64 y = __brevll(~x);
+    return ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+}
+// no bad base in [pos, pos + k)
+__device__ __forceinline__ bool range_valid(const u32* __restrict__ bad, u64 pos, int k) {
+    u64 w = pos >> 5;
+    int j = (int)(pos & 31);
+    while (k > 0) {
+        const int take = min(32 - j, k);
+        const u32 m = (take == 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << (32 - j - take);
+        if (bad[w] & m) return false;
+        k -= take;
+        j = 0;
+        w++;
+    }
+    return true;
+}
+// rank of key in a sorted dictionary of distinct keys (idx: lower bounds by the top ib bits)
+__device__ __forceinline__ bool dict_rank(const u64* __restrict__ dict, const u32* __restrict__ idx, int ib, u64 key,
+                                          u32& rank) {
+    const u32 bkt = (u32)(key >> (64 - ib));
+    u32 lo = idx[bkt];
+    const u32 end = idx[bkt + 1];
+    u32 hi = end;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (dict[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= end || dict[lo] != key) return false;
+    rank = lo;
+    return true;
+}
+// both-strand keys of the window at base position pos; bit 0 / 1 of the result = forward /
+// reverse key present
+__device__ __forceinline__ u32 wide_keys(const u64* __restrict__ codes, const u32* __restrict__ bad, u64 pos,
+                                         const Geom& g, u64& kf, u64& kr) {
+    if (!range_valid(bad, pos, g.wk)) return 0;
+    if (g.wmode == 1) {
+        const int sh = 64 - 2 * g.wlen;
+        kf = (read32(codes, pos + g.wfo) >> sh) << sh;
+        kr = revcomp32(read32(codes, pos + g.wro)) << sh;
+        return 3;
+    }
+    const int shL = 64 - 2 * g.wL, shR = 64 - 2 * g.wR;
+    const u64 head = read32(codes, pos);
+    u32 m = 0, a, b;
+    // forward strand: left = first wL bases, right = last wR bases
+    if (dict_rank(g.wdictL, g.widxL, g.wibL, (head >> shL) << shL, a) &&
+        dict_rank(g.wdictR, g.widxR, g.wibR, (read32(codes, pos + g.wk - g.wR) >> shR) << shR, b)) {
+        kf = ((u64)a << g.wshL) | ((u64)b << g.wshR);
+        m |= 1;
+    }
+    // reverse strand: left = rc(last wL bases), right = rc(first wR bases)
+    if (dict_rank(g.wdictL, g.widxL, g.wibL, revcomp32(read32(codes, pos + g.wk - g.wL)) << shL, a) &&
+        dict_rank(g.wdictR, g.widxR, g.wibR, revcomp32(head) << shR, b)) {
+        kr = ((u64)a << g.wshL) | ((u64)b << g.wshR);
+        m |= 2;
+    }
+    return m;
 }
 
 // ----------------------------------------------------------------------------
@@ -198,6 +281,7 @@ __device__ __forceinline__ bool top16_in_slice(u32 t16, const Geom& g, u32& d1) 
     return true;
 }
 
+template <int WIDE>
 __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                u64 nwords, u32* __restrict__ partial8, Geom g) {
     __shared__ u32 lhist[256];
@@ -210,6 +294,15 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
     for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
+        if (WIDE) {
+            for (int j = 0; j < 32; j++) {
+                u64 kf, kr;
+                const u32 m = wide_keys(codes, bad, w * 32 + j, g, kf, kr);
+                if ((m & 1) && slice_key(kf, g)) atomicAdd(&lhist[(u32)(kf >> 56)], 1u);
+                if ((m & 2) && slice_key(kr, g)) atomicAdd(&lhist[(u32)(kr >> 56)], 1u);
+            }
+            continue;
+        }
         u64 c0 = codes[w], c1 = codes[w + 1];
         if (cheap) {
 #pragma unroll 8
@@ -362,6 +455,7 @@ __global__ __launch_bounds__(1024) void k_scan(const u32* __restrict__ in, u32* 
 // words: generate <= 4096 keys, rank them per digit with LDS atomics, scan the 256
 // digit counts, stage the keys digit-sorted in LDS, copy the runs out.
 // ----------------------------------------------------------------------------
+template <int WIDE>
 __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                   u64 nwords, const u32* __restrict__ base1,
                                                   const u32* __restrict__ rowoff, u64* __restrict__ dst, Geom g) {
@@ -385,13 +479,23 @@ __global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes
         if (w < w1) {
             u32 b0 = bad[w], b1 = bad[w + 1];
             if (b0 != 0xFFFFFFFFu) {
-                u64 c0 = codes[w], c1 = codes[w + 1];
+                if (WIDE) {
 #pragma unroll
-                for (int jj = 0; jj < P1_PPT; jj++) {
-                    u64 kf, kr;
-                    if (window_keys(c0, c1, b0, b1, j0 + jj, g, kf, kr)) {
-                        if (slice_key(kf, g)) { key[2 * jj] = kf; vm |= 1u << (2 * jj); }
-                        if (slice_key(kr, g)) { key[2 * jj + 1] = kr; vm |= 2u << (2 * jj); }
+                    for (int jj = 0; jj < P1_PPT; jj++) {
+                        u64 kf, kr;
+                        const u32 m = wide_keys(codes, bad, w * 32 + j0 + jj, g, kf, kr);
+                        if ((m & 1) && slice_key(kf, g)) { key[2 * jj] = kf; vm |= 1u << (2 * jj); }
+                        if ((m & 2) && slice_key(kr, g)) { key[2 * jj + 1] = kr; vm |= 2u << (2 * jj); }
+                    }
+                } else {
+                    u64 c0 = codes[w], c1 = codes[w + 1];
+#pragma unroll
+                    for (int jj = 0; jj < P1_PPT; jj++) {
+                        u64 kf, kr;
+                        if (window_keys(c0, c1, b0, b1, j0 + jj, g, kf, kr)) {
+                            if (slice_key(kf, g)) { key[2 * jj] = kf; vm |= 1u << (2 * jj); }
+                            if (slice_key(kr, g)) { key[2 * jj + 1] = kr; vm |= 2u << (2 * jj); }
+                        }
                     }
                 }
             }
@@ -1271,6 +1375,83 @@ __global__ void k_cands_compact(const kr_cand* __restrict__ cur, u32 n, const u3
 // ============================================================================
 // host side
 // ============================================================================
+// ----------------------------------------------------------------------------
+// wide path (amplicon longer than one key: k > 32 or D > 16).  The 64-bit pipeline above is
+// reused three times per run with the key generators of wide_keys():
+//   phase 1  keys = `left`  of every valid window (both strands)  -> dictL = lefts  present in all genomes
+//   phase 2  keys = `right` of every valid window                 -> dictR = rights present in all genomes
+//   phase 3  keys = rank(left) : rank(right)  (exact and order preserving; a window whose left
+//            or right is in no dictionary cannot belong to a group of all genomes) -> the
+//            (left,right) groups present in all genomes, in the reference's group order
+// then the members of those groups are located in the genomes (k_wide_locate): per group and
+// diagnostic column the bases seen in the ingroup / the outgroup (the filter, Amplicon.py:495-521)
+// and, for the surviving groups, one hit (group, genome, position, strand) per member window.
+// ----------------------------------------------------------------------------
+typedef struct { u32 cand, genome, pos, strand; } wide_hit;
+
+__global__ void k_cand_prefixes(const kr_cand* __restrict__ cands, u32 n, u64* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cands[i].prefix;
+}
+
+__device__ __forceinline__ u32 code_at(const u64* __restrict__ codes, u64 p) {
+    return (u32)(codes[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3u;
+}
+
+// pass A (hitoff == nullptr): masks[(cand * 2 + side) * W + col / 16] |= 1 << (4 * (col % 16) + base), cnt[cand]++
+// pass B: hits[hitoff[cand] + cursor[cand]++] for the candidates the filter kept
+__global__ __launch_bounds__(256) void k_wide_locate(const u64* __restrict__ codes, const u32* __restrict__ bad,
+                                                    u64 npos, Geom g, const u64* __restrict__ fin,
+                                                    const u32* __restrict__ fidx, int fib, int D, int W, u32 side,
+                                                    u32 gidx, u64* __restrict__ masks, u32* __restrict__ cnt,
+                                                    const u32* __restrict__ hitoff, u32* __restrict__ cursor,
+                                                    wide_hit* __restrict__ hits) {
+    u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; pos < npos; pos += stride) {
+        if (bad[pos >> 5] == 0xFFFFFFFFu) continue;
+        u64 key[2];
+        const u32 m = wide_keys(codes, bad, pos, g, key[0], key[1]);
+        for (u32 strand = 0; strand < 2; strand++) {
+            if (!((m >> strand) & 1)) continue;
+            u32 ci;
+            if (!dict_rank(fin, fidx, fib, key[strand], ci)) continue;
+            if (hitoff == nullptr) {
+                atomicAdd(&cnt[ci], 1u);
+                u64* mrow = masks + ((u64)ci * 2 + side) * W;
+                u64 acc = 0;
+                for (int col = 0; col < D; col++) {
+                    const u32 base = strand ? 3u - code_at(codes, pos + g.wk - 1 - g.wL - col)
+                                            : code_at(codes, pos + g.wL + col);
+                    acc |= 1ull << (4 * (col & 15) + base);
+                    if ((col & 15) == 15 || col == D - 1) {
+                        atomicOr((unsigned long long*)&mrow[col >> 4], (unsigned long long)acc);
+                        acc = 0;
+                    }
+                }
+            } else {
+                const u32 o = hitoff[ci];
+                if (hitoff[ci + 1] == o) continue;
+                const u32 slot = o + atomicAdd(&cursor[ci], 1u);
+                hits[slot] = wide_hit{ci, gidx, (u32)pos, strand};
+            }
+        }
+    }
+}
+
+// keep a candidate when some diagnostic column separates the groups (or no filter is asked)
+__global__ void k_wide_filter(const u64* __restrict__ masks, u32* __restrict__ cnt, u32 n, int D, int W, int apply_filter) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!apply_filter) return;
+    bool keep = false;
+    for (int col = 0; col < D && !keep; col++) {
+        const u64 x = masks[((u64)i * 2) * W + (col >> 4)] & masks[((u64)i * 2 + 1) * W + (col >> 4)];
+        keep = ((x >> (4 * (col & 15))) & 15ull) == 0;
+    }
+    if (!keep) cnt[i] = 0;
+}
+
 static thread_local std::string g_last_error;
 
 struct DevBuf {
@@ -1335,6 +1516,15 @@ struct kr_ctx {
     int64_t fallback_launches = 0, overflow_segments = 0;
     int dbg = 0;   // KR_DBG env (test switch, results unchanged): 32 = generic intersect sub-tile path
     int isect_fmt = 0;   // KR_ISECT_FMT env (A/B switch): 1 = narrow mask format also for D <= 4
+    // wide windows (kr_set_params_wide / kr_wide_run)
+    struct Wide {
+        bool on = false;
+        int L = 0, D = 0, R = 0, k = 0, omit = 0, W = 0;
+        DevBuf dict[2], idx[2], fin, fidx, masks, cnt, hitoff, cursor, hits;
+        u32 ndict[2] = {0, 0}, nfin = 0;
+        int ib[2] = {1, 1}, fib = 1;
+        int64_t nhits = -1;
+    } wide;
 };
 
 static int fail(kr_ctx* c, int code, const char* fmt, ...) {
@@ -1527,6 +1717,11 @@ void kr_destroy(kr_ctx* c) {
     DevBuf* all[] = {&c->candA, &c->candB, &c->chunkcnt,
                      &c->chunkpos, &c->flags, &c->blockcnt, &c->blockpos, &c->other, &c->records, &c->nrec, &c->fbdesc, &c->fbsegs};
     for (DevBuf* b : all) release(c, *b);
+    {
+        auto& w = c->wide;
+        DevBuf* wb[] = {&w.dict[0], &w.dict[1], &w.idx[0], &w.idx[1], &w.fin, &w.fidx, &w.masks, &w.cnt, &w.hitoff, &w.cursor, &w.hits};
+        for (DevBuf* b : wb) release(c, *b);
+    }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
@@ -1546,6 +1741,47 @@ static Geom slice_geom(const kr_ctx* c, u32 slice) {
     return g;
 }
 
+// absolute + relative geometry of (L, D, R) windows sorted in 4^sb slices with fan-out 2^b
+static Geom make_geom(int L, int D, int R, int omit, int sb, int b) {
+    Geom g{};
+    const int k = L + D + R;
+    g.k = k; g.L = L; g.D = D; g.R = R;
+    g.sR = 2 * D;
+    g.sD = 2 * R;
+    g.topmask = topbits(2 * k);
+    g.mL = topbits(2 * L);
+    g.mR = topbits(2 * (L + R)) & ~g.mL;
+    g.mD = topbits(2 * k) & ~topbits(2 * (L + R));
+    g.omit = omit;
+    g.sbits = 2 * sb;
+    g.slice = 0;
+    g.LRrel = L - sb + R;
+    g.pmask = topbits(2 * g.LRrel);
+    g.b = b;
+    g.rb = 64 - b;
+    return g;
+}
+
+// key-space slices: one sort unit holds at most ~4.2e8 keys (fine buckets of <= 1600 keys at the
+// largest fan-out b = 18); larger genomes are sorted in 4^sb slices by the first sb bases of `left`.
+// fan-out: average fine bucket of ~1600 keys or fewer (limit LS_CAP - LS_T = 2048), 8 <= b <= 18
+static int plan_sort(kr_ctx* c, size_t max_bases, int Lmin, int& sb, int& b) {
+    const u64 nmax = 2 * (u64)max_bases;
+    sb = 0;
+    while (sb < 4 && (nmax >> (2 * sb)) > (BUCKET_AVG << 18)) sb++;
+    if (const char* e = getenv("KR_SLICE_BASES")) sb = std::max(0, std::min(4, atoi(e)));
+    if (sb > Lmin) {
+        if (getenv("KR_SLICE_BASES")) sb = Lmin;
+        else return fail(c, KR_ERR_PARAM, "a genome of %zu bases needs %d slice bases but conserved-left is %d", max_bases, sb, Lmin);
+    }
+    if ((nmax >> (2 * sb)) > (BUCKET_AVG << 18) * 4)
+        return fail(c, KR_ERR_PARAM, "genome of %zu bases is too large for %d slice bases", max_bases, sb);
+    const u64 per_slice = nmax >> (2 * sb);
+    b = 8;
+    while (b < 18 && (per_slice >> b) > BUCKET_AVG) b++;
+    return KR_OK;
+}
+
 int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_bases) {
     if (!c) return KR_ERR_PARAM;
     const int k = L + D + R;
@@ -1556,40 +1792,37 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
         return fail(c, KR_ERR_PARAM, "unknown softmask mode %d", softmask_mode);
     if (!c->genomes.empty()) return fail(c, KR_ERR_STATE, "kr_set_params after genomes were uploaded");
     if (max_bases >= (1ull << 32) - 64) return fail(c, KR_ERR_PARAM, "genomes of >= 2^32 bases are not supported");
-    Geom g{};
-    g.k = k; g.L = L; g.D = D; g.R = R;
-    g.sR = 2 * D;
-    g.sD = 2 * R;
-    g.topmask = topbits(2 * k);
-    g.mL = topbits(2 * L);
-    g.mR = topbits(2 * (L + R)) & ~g.mL;
-    g.mD = topbits(2 * k) & ~topbits(2 * (L + R));
-    g.omit = softmask_mode == KR_SOFT_OMIT;
-    // key-space slices: one sort unit holds at most ~4.2e8 keys (fine buckets of <= 1600 keys at the
-    // largest fan-out b = 18); larger genomes are sorted in 4^sb slices by the first sb bases of `left`
-    const u64 nmax = 2 * (u64)max_bases;
-    int sb = 0;
-    while (sb < 4 && (nmax >> (2 * sb)) > (BUCKET_AVG << 18)) sb++;
-    if (const char* e = getenv("KR_SLICE_BASES")) sb = std::max(0, std::min(4, atoi(e)));
-    if (sb > L) {
-        if (getenv("KR_SLICE_BASES")) sb = L;
-        else return fail(c, KR_ERR_PARAM, "a genome of %zu bases needs %d slice bases but conserved-left is %d", max_bases, sb, L);
-    }
-    if ((nmax >> (2 * sb)) > (BUCKET_AVG << 18) * 4)
-        return fail(c, KR_ERR_PARAM, "genome of %zu bases is too large for %d slice bases", max_bases, sb);
+    int sb, b, rc;
+    if ((rc = plan_sort(c, max_bases, L, sb, b))) return rc;
     c->sb = sb;
     c->nslices = 1 << (2 * sb);
-    g.sbits = 2 * sb;
-    g.slice = 0;
-    g.LRrel = L - sb + R;
-    g.pmask = topbits(2 * g.LRrel);
-    // fan-out: average fine bucket of ~1600 keys or fewer (limit LS_CAP - LS_T = 2048), 8 <= b <= 18
-    const u64 per_slice = nmax >> (2 * sb);
-    int b = 8;
-    while (b < 18 && (per_slice >> b) > BUCKET_AVG) b++;
-    g.b = b;
-    g.rb = 64 - b;
-    c->g = g;
+    c->g = make_geom(L, D, R, softmask_mode == KR_SOFT_OMIT, sb, b);
+    c->max_bases = max_bases;
+    c->have_params = true;
+    c->wide.on = false;
+    return KR_OK;
+}
+
+int kr_set_params_wide(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_bases) {
+    if (!c) return KR_ERR_PARAM;
+    const int k = L + D + R;
+    if (L < 1 || L > 32 || R < 1 || R > 32 || D < 0 || k > KR_WIDE_MAX_K)
+        return fail(c, KR_ERR_PARAM, "wide path needs 1 <= L, R <= 32 and L+D+R <= %d (got %d/%d/%d)", KR_WIDE_MAX_K, L, D, R);
+    if (softmask_mode != KR_SOFT_MAP && softmask_mode != KR_SOFT_OMIT)
+        return fail(c, KR_ERR_PARAM, "unknown softmask mode %d", softmask_mode);
+    if (!c->genomes.empty()) return fail(c, KR_ERR_STATE, "kr_set_params_wide after genomes were uploaded");
+    if (max_bases >= (1ull << 32) - 256) return fail(c, KR_ERR_PARAM, "genomes of >= 2^32 bases are not supported");
+    int sb, b, rc;
+    if ((rc = plan_sort(c, max_bases, std::min(L, R), sb, b))) return rc;
+    c->sb = sb;
+    c->nslices = 1 << (2 * sb);
+    auto& w = c->wide;
+    w.on = true;
+    w.L = L; w.D = D; w.R = R; w.k = k;
+    w.omit = softmask_mode == KR_SOFT_OMIT;
+    w.W = (D + 15) / 16;
+    w.nhits = -1;
+    c->g = make_geom(L, 0, 0, w.omit, sb, b);    // placeholder until kr_wide_run picks a phase
     c->max_bases = max_bases;
     c->have_params = true;
     return KR_OK;
@@ -1612,7 +1845,7 @@ static int alloc_slice(kr_ctx* c, Slice& S, u64 count) {
 // per-lane scratch for sorting slices of up to `maxcount` keys from genomes of up to max_bases
 static int ensure_lanes(kr_ctx* c, u64 maxcount) {
     const u32 nb = 1u << c->g.b;
-    const u64 mw = (c->max_bases + 31) / 32 + 4;
+    const u64 mw = (c->max_bases + 31) / 32 + PAD_WORDS + 2;
     const u64 ntmax = maxcount / P2_TILE + 260;
     int rc;
     for (int i = 0; i < c->nlanes; i++) {
@@ -1630,10 +1863,57 @@ static int ensure_lanes(kr_ctx* c, u64 maxcount) {
 }
 
 static void launch_pack(kr_ctx* c, Genome& G, Lane& ln, hipStream_t st) {
-    const u64 nwp = G.nwords + 2;   // two pad words (all bad) so window j may read word w+1
+    const u64 nwp = G.nwords + PAD_WORDS;   // pad words (all bad): a window may read past the last base
     u32 grid = (u32)std::min<u64>((nwp + 255) / 256, 4096);
     hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, st, (const uint8_t*)G.bases.p, (u64)G.n_bases,
                        (u64*)ln.codes.p, (u32*)ln.bad.p, nwp, c->g.omit);
+}
+
+static void launch_hist8(kr_ctx* c, Genome& G, Lane& ln, hipStream_t st, const Geom& g) {
+    if (g.wmode)
+        hipLaunchKernelGGL(k_hist8<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
+                           G.nwords, (u32*)ln.partial8.p, g);
+    else
+        hipLaunchKernelGGL(k_hist8<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
+                           G.nwords, (u32*)ln.partial8.p, g);
+}
+
+// exact key count of every slice under the current geometry (sizes the slice arrays):
+// pack + top-byte histogram on the main stream
+static int count_slices(kr_ctx* c, Genome& G) {
+    int rc;
+    if ((rc = ensure_lanes(c, 16))) return rc;
+    hipStream_t st = c->stream;
+    Lane& ln = c->lanes[0];
+    launch_pack(c, G, ln, st);
+    if ((int)G.sl.size() != c->nslices) {
+        for (Slice& S : G.sl) {
+            release(c, S.keys); release(c, S.off); release(c, S.chunkstart); release(c, S.chunkdesc); release(c, S.ovf);
+        }
+        G.sl.assign(c->nslices, Slice());
+    }
+    std::vector<u32> tot(256);
+    u64 maxcount = 0;
+    G.nmax = 0;
+    G.sorted = G.finalized = false;
+    G.count = -1;
+    for (int s = 0; s < c->nslices; s++) {
+        const Geom gs = slice_geom(c, (u32)s);
+        launch_hist8(c, G, ln, st, gs);
+        hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+        HIPCHK(c, hipMemcpyAsync(tot.data(), (u32*)ln.base1.p + 260, 256 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        u64 cnt = 0;
+        for (u32 v : tot) cnt += v;
+        if (cnt >= (1ull << 31))
+            return fail(c, KR_ERR_CAPACITY, "slice %d of genome %d holds %llu keys (>= 2^31): raise KR_SLICE_BASES", s,
+                        G.id, (unsigned long long)cnt);
+        if ((rc = alloc_slice(c, G.sl[s], cnt))) return rc;
+        G.nmax += cnt;
+        maxcount = std::max(maxcount, cnt);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ensure_lanes(c, maxcount);
 }
 
 int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
@@ -1649,39 +1929,13 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
     G.count = -1;
     int rc;
     if ((rc = ensure(c, G.bases, n + 64))) return rc;
-    if ((rc = ensure_lanes(c, 16))) return rc;
-    hipStream_t st = c->stream;
-    if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, st));
-    // exact key count of every slice (sizes the slice arrays): pack + top-byte histogram
-    Lane& ln = c->lanes[0];
-    launch_pack(c, G, ln, st);
-    if ((int)G.sl.size() != c->nslices) {
-        for (Slice& S : G.sl) {
-            release(c, S.keys); release(c, S.off); release(c, S.chunkstart); release(c, S.chunkdesc); release(c, S.ovf);
-        }
-        G.sl.assign(c->nslices, Slice());
+    if (n) HIPCHK(c, hipMemcpyAsync(G.bases.p, bases, n, hipMemcpyHostToDevice, c->stream));
+    if (c->wide.on) {            // the slices are counted per phase by kr_wide_run
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        G.uploaded = true;
+        return KR_OK;
     }
-    std::vector<u32> tot(256);
-    u64 maxcount = 0;
-    G.nmax = 0;
-    for (int s = 0; s < c->nslices; s++) {
-        const Geom gs = slice_geom(c, (u32)s);
-        hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
-                           G.nwords, (u32*)ln.partial8.p, gs);
-        hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
-        HIPCHK(c, hipMemcpyAsync(tot.data(), (u32*)ln.base1.p + 260, 256 * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        u64 cnt = 0;
-        for (u32 v : tot) cnt += v;
-        if (cnt >= (1ull << 31))
-            return fail(c, KR_ERR_CAPACITY, "slice %d of genome %d holds %llu keys (>= 2^31): raise KR_SLICE_BASES", s,
-                        id, (unsigned long long)cnt);
-        if ((rc = alloc_slice(c, G.sl[s], cnt))) return rc;
-        G.nmax += cnt;
-        maxcount = std::max(maxcount, cnt);
-    }
-    HIPCHK(c, hipGetLastError());
-    if ((rc = ensure_lanes(c, maxcount))) return rc;
+    if ((rc = count_slices(c, G))) return rc;
     G.uploaded = true;
     return KR_OK;
 }
@@ -1690,6 +1944,7 @@ int kr_genome_sort(kr_ctx* c, int id) {
     if (!c) return KR_ERR_PARAM;
     auto it = c->genomes.find(id);
     if (it == c->genomes.end() || !it->second.uploaded) return fail(c, KR_ERR_STATE, "genome %d not uploaded", id);
+    if (it->second.sl.empty()) return fail(c, KR_ERR_STATE, "genome %d has no slice plan (wide windows: use kr_wide_run)", id);
     HIPCHK(c, hipSetDevice(c->device));
     Genome& G = it->second;
     const u32 nb = 1u << c->g.b;
@@ -1711,8 +1966,7 @@ int kr_genome_sort(kr_ctx* c, int id) {
         S.count = -1;
         {
             StageScope sc(c, KR_ST_HIST8, st);
-            hipLaunchKernelGGL(k_hist8, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                               (u32*)ln.partial8.p, g);
+            launch_hist8(c, G, ln, st, g);
         }
         {
             StageScope sc(c, KR_ST_REDUCE8, st);
@@ -1725,8 +1979,12 @@ int kr_genome_sort(kr_ctx* c, int id) {
         u64* pass1_dst = g.b > 8 ? (u64*)ln.tmpkeys.p : (u64*)S.keys.p;
         {
             StageScope sc(c, KR_ST_SCATTER1, st);
-            hipLaunchKernelGGL(k_scatter1, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                               (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
+            if (g.wmode)
+                hipLaunchKernelGGL(k_scatter1<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad,
+                                   G.nwords, (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
+            else
+                hipLaunchKernelGGL(k_scatter1<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad,
+                                   G.nwords, (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
         }
         if (g.b > 8) {
             const u32 ntmax = (u32)(S.nmax / P2_TILE) + 257;
@@ -2149,6 +2407,155 @@ int64_t kr_fetch(kr_ctx* c, kr_record* out, size_t cap) {
     if (c->nrecords)
         HIPCHK(c, hipMemcpy(out, c->records.p, (size_t)c->nrecords * sizeof(kr_record), hipMemcpyDeviceToHost));
     return c->nrecords;
+}
+
+// ----------------------------------------------------------------------------
+// wide path driver
+// ----------------------------------------------------------------------------
+static int ceil_log2(u64 n) { int b = 0; while ((1ull << b) < n) b++; return b; }
+
+// sort every listed genome under the current c->g and intersect them (no filter): the
+// candidates' prefixes, dense and sorted, go to `out` with a top-bits index
+static int64_t wide_phase(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, DevBuf& out, DevBuf& idx, int& ib,
+                          int keybits) {
+    int rc;
+    for (int i = 0; i < n; i++) {
+        Genome& G = c->genomes[ids[i]];
+        if ((rc = count_slices(c, G))) return rc;
+        if ((rc = kr_genome_sort(c, ids[i]))) return rc;
+    }
+    int64_t nc = kr_intersect(c, ids, n, is_in, 0);
+    if (nc < 0) return nc;
+    if (nc >= (1ll << 32) - 1) return fail(c, KR_ERR_CAPACITY, "wide path: %lld dictionary entries (>= 2^32)", (long long)nc);
+    ib = std::max(1, std::min(std::min(22, keybits), ceil_log2((u64)nc + 1) - 2));
+    if ((rc = ensure(c, out, ((size_t)nc + 2) * 8))) return rc;
+    if ((rc = ensure(c, idx, (((size_t)1 << ib) + 2) * 4))) return rc;
+    hipStream_t st = c->stream;
+    if (nc)
+        hipLaunchKernelGGL(k_cand_prefixes, dim3(((u32)nc + 255) / 256), dim3(256), 0, st, (const kr_cand*)c->candB.p,
+                           (u32)nc, (u64*)out.p);
+    const u32 nbk = 1u << ib;
+    hipLaunchKernelGGL(k_offsets_from_sorted, dim3((nbk + 1 + 255) / 256), dim3(256), 0, st, (const u64*)out.p, (u32)nc,
+                       nbk, 64 - ib, (u32*)idx.p);
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    return nc;
+}
+
+int64_t kr_wide_run(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int apply_filter) {
+    if (!c || !c->wide.on) return fail(c, KR_ERR_STATE, "kr_set_params_wide first");
+    if (n < 1 || n > MAXG) return fail(c, KR_ERR_PARAM, "kr_wide_run: 1 .. %d genomes per call", MAXG);
+    for (int i = 0; i < n; i++) {
+        auto it = c->genomes.find(ids[i]);
+        if (it == c->genomes.end() || !it->second.uploaded) return fail(c, KR_ERR_STATE, "genome %d not uploaded", ids[i]);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& w = c->wide;
+    w.nhits = -1;
+    w.nfin = 0;
+    const int sb = c->sb, b = c->g.b;
+    // phase 1 / 2: the `left` / `right` spectra present in all genomes
+    for (int ph = 0; ph < 2; ph++) {
+        const int len = ph == 0 ? w.L : w.R;
+        Geom g = make_geom(len, 0, 0, w.omit, sb, b);
+        g.wmode = 1;
+        g.wk = w.k;
+        g.wlen = len;
+        g.wfo = ph == 0 ? 0 : w.k - w.R;
+        g.wro = ph == 0 ? w.k - w.L : 0;
+        c->g = g;
+        int64_t nd = wide_phase(c, ids, n, is_in, w.dict[ph], w.idx[ph], w.ib[ph], 2 * len);
+        if (nd < 0) return nd;
+        w.ndict[ph] = (u32)nd;
+        if (nd == 0) { w.nhits = 0; return 0; }
+    }
+    // phase 3: composite keys rank(left) : rank(right)
+    {
+        int bitsL = std::max(1, ceil_log2(w.ndict[0])), bitsR = std::max(1, ceil_log2(w.ndict[1]));
+        if ((bitsL + bitsR) & 1) bitsR++;
+        while (bitsL + bitsR < 2 * sb + 2) bitsR += 2;       // room for the slice digits
+        const int half = (bitsL + bitsR) / 2;
+        Geom g = make_geom(half, 0, 0, w.omit, sb, b);
+        g.wmode = 2;
+        g.wk = w.k;
+        g.wL = w.L;
+        g.wR = w.R;
+        g.wshL = 64 - bitsL;
+        g.wshR = 64 - bitsL - bitsR;
+        g.wibL = w.ib[0];
+        g.wibR = w.ib[1];
+        g.wdictL = (const u64*)w.dict[0].p;
+        g.wdictR = (const u64*)w.dict[1].p;
+        g.widxL = (const u32*)w.idx[0].p;
+        g.widxR = (const u32*)w.idx[1].p;
+        c->g = g;
+        int64_t nf = wide_phase(c, ids, n, is_in, w.fin, w.fidx, w.fib, bitsL + bitsR);
+        if (nf < 0) return nf;
+        w.nfin = (u32)nf;
+        if (nf == 0) { w.nhits = 0; return 0; }
+    }
+    // members of the groups: masks + counts, filter, hits
+    int rc;
+    const u32 nf = w.nfin;
+    const int W = std::max(1, w.W);
+    if ((rc = ensure(c, w.masks, (size_t)nf * 2 * W * 8))) return rc;
+    if ((rc = ensure(c, w.cnt, ((size_t)nf + 4) * 4))) return rc;
+    if ((rc = ensure(c, w.hitoff, ((size_t)nf + 4) * 4))) return rc;
+    if ((rc = ensure(c, w.cursor, ((size_t)nf + 4) * 4))) return rc;
+    hipStream_t st = c->stream;
+    if ((rc = join_lanes(c))) return rc;
+    HIPCHK(c, hipMemsetAsync(w.masks.p, 0, (size_t)nf * 2 * W * 8, st));
+    HIPCHK(c, hipMemsetAsync(w.cnt.p, 0, ((size_t)nf + 4) * 4, st));
+    HIPCHK(c, hipMemsetAsync(w.cursor.p, 0, ((size_t)nf + 4) * 4, st));
+    Lane& ln = c->lanes[0];
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < n; i++) {
+            Genome& G = c->genomes[ids[i]];
+            if (G.n_bases == 0) continue;
+            launch_pack(c, G, ln, st);
+            const u32 grid = (u32)std::min<u64>((G.n_bases + 255) / 256, 16384);
+            hipLaunchKernelGGL(k_wide_locate, dim3(grid), dim3(256), 0, st, (const u64*)ln.codes.p,
+                               (const u32*)ln.bad.p, (u64)G.n_bases, c->g, (const u64*)w.fin.p, (const u32*)w.fidx.p,
+                               w.fib, w.D, W, is_in[i] ? 0u : 1u, (u32)i, (u64*)w.masks.p, (u32*)w.cnt.p,
+                               pass ? (const u32*)w.hitoff.p : (const u32*)nullptr, (u32*)w.cursor.p,
+                               (wide_hit*)w.hits.p);
+        }
+        if (pass == 0) {
+            hipLaunchKernelGGL(k_wide_filter, dim3((nf + 255) / 256), dim3(256), 0, st, (const u64*)w.masks.p,
+                               (u32*)w.cnt.p, nf, w.D, W, apply_filter ? 1 : 0);
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)w.cnt.p, (u32*)w.hitoff.p, nf);
+            u32 total = 0;
+            HIPCHK(c, hipMemcpyAsync(&total, (u32*)w.hitoff.p + nf, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipGetLastError());
+            w.nhits = total;
+            if (total == 0) return 0;
+            if ((rc = ensure(c, w.hits, ((size_t)total + 2) * sizeof(wide_hit)))) return rc;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    return w.nhits;
+}
+
+int64_t kr_wide_fetch(kr_ctx* c, int what, void* out, size_t cap_bytes) {
+    if (!c || !c->wide.on) return fail(c, KR_ERR_STATE, "kr_set_params_wide first");
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& w = c->wide;
+    const void* src = nullptr;
+    size_t n = 0, esz = 8;
+    switch (what) {
+    case KR_WIDE_DICT_LEFT: src = w.dict[0].p; n = w.ndict[0]; break;
+    case KR_WIDE_DICT_RIGHT: src = w.dict[1].p; n = w.ndict[1]; break;
+    case KR_WIDE_GROUPS: src = w.fin.p; n = w.nfin; break;
+    case KR_WIDE_HITS: src = w.hits.p; n = w.nhits > 0 ? (size_t)w.nhits : 0; esz = sizeof(wide_hit); break;
+    default: return fail(c, KR_ERR_PARAM, "kr_wide_fetch: unknown selector %d", what);
+    }
+    if (!out) return (int64_t)n;       // size query
+    if (n * esz > cap_bytes) return fail(c, KR_ERR_CAPACITY, "kr_wide_fetch: buffer too small (%zu bytes needed)", n * esz);
+    HIPCHK(c, hipDeviceSynchronize());
+    if (n) HIPCHK(c, hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost));
+    return (int64_t)n;
 }
 
 int kr_sync(kr_ctx* c) {

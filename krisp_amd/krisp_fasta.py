@@ -56,14 +56,91 @@ class UnsupportedGeometry(NotImplementedError):
     pass
 
 
+class MixedAlphabet(NotImplementedError):
+    """DNA and RNA genomes in one run: the reference compares their k-mers as text ('T' never
+    equals 'U', kstream.py:481-508, 599), which the 2-bit device alphabet cannot express."""
+
+
+def _to_rna(groups):
+    """kstream writes an RNA genome's k-mers back with U (kstream.py:297, 599)"""
+    for g in groups:
+        for a in g:
+            a.left, a.diag, a.right = (x.replace("T", "U") for x in (a.left, a.diag, a.right))
+    return groups
+
+
 def _check_geometry(L, D, R):
+    """geometries of the packed path: the whole amplicon in one 64-bit key"""
     k = L + D + R
     if k > 32:
         raise UnsupportedGeometry(
-            f"amplicon length {k} > 32: the multi-word key path is not built yet "
-            "(a 64-bit key holds 32 bases)")
+            f"amplicon length {k} > 32: only the fused flow (find_regions / the command line) "
+            "carries amplicons longer than one 64-bit key")
     if D > 16:
         raise UnsupportedGeometry(f"diagnostic length {D} > 16 exceeds the device mask format")
+
+
+def _is_wide(L, D, R):
+    return L + D + R > 32 or D > 16
+
+
+def _check_wide(L, D, R):
+    """geometries of the wide path (kr_wide_run): `left` and `right` in one key each"""
+    from . import _native
+    if not (1 <= L <= 32 and 1 <= R <= 32 and L + D + R <= _native.WIDE_MAX_K):
+        raise UnsupportedGeometry(
+            f"{L}/{D}/{R}: amplicons longer than 32 bases need 1 <= conserved-left, conserved-right "
+            f"<= 32 and a length <= {_native.WIDE_MAX_K}")
+
+
+_COMP_U8 = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP_U8[_a] = _b
+
+
+def _groups_from_hits(hits, texts, labels, L, D, R):
+    """kr_wide_run hits (group, genome, position, strand) -> groups of amplicon.Amplicon in the
+    reference's order: groups by (left,right), sequences by diag; the window text is cut from
+    the genome the host already holds (soft-mask mapped, kstream.py:622-642; reverse
+    complemented for strand 1, kstream.py:644-659)."""
+    if len(hits) == 0:
+        return []
+    k = L + D + R
+    ar = np.arange(k, dtype=np.int64)
+    rows = []
+    for gi, text in enumerate(texts):
+        sel = hits[hits["genome"] == gi]
+        if len(sel) == 0:
+            continue
+        t = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        W = t[sel["pos"].astype(np.int64)[:, None] + ar] & np.uint8(0xDF)
+        rc = sel["strand"] == 1
+        W[rc] = _COMP_U8[W[rc][:, ::-1]]
+        row = np.empty((len(sel), k + 8), dtype=np.uint8)
+        row[:, 0:4] = sel["cand"].astype(">u4").view(np.uint8).reshape(-1, 4)
+        row[:, 4:4 + L] = W[:, :L]
+        row[:, 4 + L:4 + L + R] = W[:, L + D:]
+        row[:, 4 + L + R:4 + k] = W[:, L:L + D]
+        row[:, 4 + k:] = np.full(len(sel), gi, dtype=">u4").view(np.uint8).reshape(-1, 4)
+        rows.append(row)
+    uniq, counts = np.unique(np.concatenate(rows), axis=0, return_counts=True)
+    groups, last_cand, last_seq = [], None, None
+    for row, cnt in zip(uniq, counts):
+        cand = bytes(row[0:4])
+        seq = bytes(row[4:4 + k])
+        gi = int.from_bytes(bytes(row[4 + k:]), "big")
+        if cand != last_cand:
+            groups.append([])
+            last_cand, last_seq = cand, None
+        if seq != last_seq:
+            txt = seq.decode("ascii")
+            groups[-1].append(amplicon.Amplicon(txt[:L], txt[L + R:], txt[L:L + R], []))
+            last_seq = seq
+        groups[-1][-1].labels.extend([labels[gi]] * int(cnt))
+    for g in groups:
+        for a in g:
+            a.labels.sort()
+    return groups
 
 
 # ----------------------------------------------------------------------------
@@ -144,7 +221,7 @@ def _merge_groups(device_groups, touched, special_groups):
 # the fused device flow used by main()
 # ----------------------------------------------------------------------------
 def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,
-                 device=0, verbose=False, keep_merged=False):
+                 device=0, verbose=False, keep_merged=False, wide=None):
     """FASTA files -> list of surviving groups (amplicon.Amplicon lists).
 
     = extractSortedKmers per file + mergeFiles + filterAlignments of the reference
@@ -155,12 +232,17 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     k = amplicon_len
     D_nominal = k - L - R
     Le, De, Re = codec.effective_geometry(L, D_nominal, R)
-    _check_geometry(Le, De, Re)
     files = list(ingroup_files) + list(outgroup_files)
     # the reference filters whenever k > L + R (krisp_fasta.py:265); with R == 0 the
     # diagnostic column is empty (kstream.py:824-830) and every group fails the filter
     do_filter = k > L + R
     quirk_all_fail = do_filter and De == 0
+    if wide is None:                 # (tests force the wide path on packable geometries)
+        wide = _is_wide(Le, De, Re)
+    if wide and not quirk_all_fail:
+        _check_wide(Le, De, Re)
+    elif not wide:
+        _check_geometry(Le, De, Re)
     t0 = time.time()
     # ingest: files are read, inflated and parsed concurrently (the parser releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
@@ -168,6 +250,10 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
         loaded = list(pool.map(lambda f: fasta.ingest(f, k, omit_soft), files))
     texts = [b for b, _, _ in loaded]
     specials = [[codec.split_window(w, Le, De, Re) for w in sp] for _, _, sp in loaded]
+    rna = [bool(r) for _, r, _ in loaded]
+    if any(rna) and not all(rna):
+        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+    finish = _to_rna if all(rna) else (lambda groups: groups)
     if len(files) == 1:
         # mergeFiles moves the lone k-mer file; its lines carry no label, so later stages
         # label them with the file they read: simplename('merged_file.txt') (shared.py:373)
@@ -178,6 +264,23 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     flags = [lab in ingroup_labels for lab in labels]
     stats = {"read_s": time.time() - t0}
     t1 = time.time()
+    if wide:
+        if quirk_all_fail:
+            stats.update(device_s=0.0, kmers=0, candidates=0)
+            return [], stats
+        if any(specials):
+            raise fasta.IupacWindowsUnsupported(
+                "IUPAC ambiguity letters inside amplicons longer than 32 bases are not carried yet")
+        with _native.Engine(device=device) as eng:
+            eng.set_params_wide(Le, De, Re, omit_soft=omit_soft, max_bases=max(len(t) for t in texts))
+            ids = list(range(len(files)))
+            for i, t in enumerate(texts):
+                eng.upload(i, t)
+            nhits = eng.wide_run(ids, flags, apply_filter=do_filter)
+            hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
+            ngroups = len(eng.wide_fetch(_native.WIDE_GROUPS))
+        stats.update(device_s=time.time() - t1, kmers=0, candidates=ngroups)
+        return finish(_groups_from_hits(hits, texts, labels, Le, De, Re)), stats
     with _native.Engine(device=device) as eng:
         eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(len(t) for t in texts))
         counts = []
@@ -202,7 +305,7 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
     if touched:
         groups = _merge_groups(groups, touched, sgroups)
-    return groups, stats
+    return finish(groups), stats
 
 
 # ----------------------------------------------------------------------------

@@ -48,8 +48,9 @@ def _run_main(argv):
     return buf.getvalue()
 
 
-@pytest.mark.parametrize("case", [c for c in PACKABLE if "csv" in c], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in FC if "csv" in c], ids=lambda c: c["name"])
 def test_cli_output_is_byte_identical_to_the_reference(case, tmp_path):
+    """every golden case, the amplicons longer than one key (30/40/30, 32/60/32 ...) included"""
     paths = _paths(case, tmp_path)
     argv = [paths[f] for f in case["ingroup"]]
     if case["outgroup"]:
@@ -95,12 +96,86 @@ def test_stage_functions_match_reference_intermediates(case, tmp_path):
 
 
 @pytest.mark.parametrize("case", TOO_LONG, ids=lambda c: c["name"])
-def test_amplicons_longer_than_32_fail_loudly(case, tmp_path):
+def test_wide_amplicons_match_reference_intermediates(case, tmp_path):
+    """k > 32: the fused flow reproduces the reference's filtered (or merged) file; the
+    file-per-stage functions have no wide form and say so."""
+    from krisp_amd import amplicon
     from krisp_amd import krisp_fasta as KF
     paths = _paths(case, tmp_path)
+    groups, stats = KF.find_regions([paths[f] for f in case["ingroup"]], [paths[f] for f in case["outgroup"]],
+                                    case["L"], case["R"], _amplicon(case), omit_soft=case["omit_soft"])
+    want = case["filtered_canon"] if "filtered_canon" in case else case["merged_canon"]
+    assert sorted(amplicon.merged_lines(groups)) == want
+    if "filtered_canon" in case:
+        assert stats["candidates"] == len({tuple(ln.split(",")[0:3:2]) for ln in case["merged_canon"]})
     with pytest.raises(KF.UnsupportedGeometry):
-        KF.find_regions([paths[f] for f in case["ingroup"]], [paths[f] for f in case["outgroup"]],
-                        case["L"], case["R"], _amplicon(case), omit_soft=case["omit_soft"])
+        KF.extractSortedKmers(paths[case["ingroup"][0]], case["L"], case["R"], _amplicon(case),
+                              str(tmp_path / "x.kmers"), "80%", 1, False, case["omit_soft"])
+
+
+def test_geometries_beyond_the_wide_path_fail_loudly(tmp_path):
+    from krisp_amd import krisp_fasta as KF
+    d = os.path.join(GOLDEN, "c1")
+    ing = [f"{d}/ingroup0.fasta.gz", f"{d}/ingroup1.fasta.gz"]
+    with pytest.raises(KF.UnsupportedGeometry):
+        KF.find_regions(ing, [], 33, 20, 80)          # conserved-left longer than one key
+    with pytest.raises(KF.UnsupportedGeometry):
+        KF.find_regions(ing, [], 30, 30, 200)         # longer than KR_WIDE_MAX_K
+    assert KF.find_regions(ing, [], 30, 0, 60)[0] == []   # R = 0 quirk: every group fails the filter
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatch):
+    """kr_wide_run (three sorts + locate) against the text-level oracle: k > 32 and D > 16,
+    soft masking, N runs, repeats, several records, with and without key-space slices."""
+    import random
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    from oracle import krisp_oracle as O
+    rng = random.Random(7000 + seed)
+    L, D, R = rng.choice([(12, 10, 12), (4, 30, 3), (6, 18, 6), (32, 5, 32), (20, 0, 20), (1, 40, 1),
+                          (16, 17, 3), (9, 64, 9), (32, 64, 32), (5, 24, 8)])
+    if seed % 4 == 3:
+        monkeypatch.setenv("KR_SLICE_BASES", "1")
+    n_in, n_out = rng.randint(1, 3), rng.randint(0, 2)
+    if n_in + n_out == 1:
+        n_out = 1
+    n = rng.randint(300, 3000)
+    anc = [rng.choice("ACGT") for _ in range(n)]
+    if rng.random() < 0.5:                      # a repeat: the same window at several places
+        a, ln = rng.randrange(n // 2), rng.randint(40, 200)
+        anc[n // 2:n // 2 + ln] = anc[a:a + ln]
+    ing, outg = [], []
+    as_rna = rng.random() < 0.25
+    for gi in range(n_in + n_out):
+        s = list(anc)
+        for _ in range(rng.randint(0, max(1, n // 60))):
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        for _ in range(rng.randint(0, 3)):
+            a = rng.randrange(len(s))
+            s[a:a + rng.randint(1, 4)] = "N" * rng.randint(1, 4)
+        if rng.random() < 0.6:
+            a = rng.randrange(len(s))
+            w = rng.randint(3, 60)
+            s[a:a + w] = [c.lower() for c in s[a:a + w]]
+        cut = rng.randrange(len(s))
+        text = ">r1\n" + "".join(s[:cut]) + "\n>r2 x\n" + "".join(s[cut:]) + "\n"
+        if as_rna:
+            text = text.replace("T", "U").replace("t", "u")
+        fn = f"{'in' if gi < n_in else 'out'}{gi}.fa"
+        p = tmp_path / fn
+        p.write_text(text)
+        (ing if gi < n_in else outg).append(str(p))
+    omit = rng.random() < 0.3
+    k = L + D + R
+    sf = [(f"{O.basename(f)}.{k}mers", O.extract_sorted_kmers(f, L, R, k, omit)) for f in ing + outg]
+    merged = O.merge_tree(sf)
+    expect = O.filter_lines(merged, [O.simplename(f) for f in ing]) if D > 0 else merged
+    groups, _ = KF.find_regions(ing, outg, L, R, k, omit_soft=omit)
+    got = amplicon.merged_lines(groups)
+    assert sorted(got) == sorted(expect)
+    pairs = [tuple(ln.split(",")[0:3:2]) for ln in got]
+    assert pairs == sorted(pairs)               # groups ascend by (left, right)
 
 
 def _geo(kwargs):

@@ -100,3 +100,69 @@ def test_c5_three_gbp_genomes():
     c1, info = _run(fam, 28, 1, 2)
     assert info["nslices"] == 16
     print("C5:", len(c1), "candidates;", info)
+
+
+def _groups_packed(fam, L, D, R, do_filter):
+    from krisp_amd import _native, amplicon
+    ids = list(range(len(fam)))
+    with _native.Engine() as eng:
+        eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            eng.upload(i, t)
+            eng.sort(i)
+        n = eng.intersect(ids, [f for _, f, _ in fam], apply_filter=do_filter)
+        recs = eng.collect(ids) if n else np.empty(0, dtype=_native.RECORD)
+    return amplicon.groups_from_records(recs, [nm for nm, _, _ in fam], L, D, R)
+
+
+def _groups_wide(fam, L, D, R, do_filter):
+    from krisp_amd import _native
+    from krisp_amd import krisp_fasta as KF
+    ids = list(range(len(fam)))
+    with _native.Engine() as eng:
+        eng.set_params_wide(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            eng.upload(i, t)
+        n = eng.wide_run(ids, [f for _, f, _ in fam], apply_filter=do_filter)
+        hits = eng.wide_fetch(_native.WIDE_HITS) if n else np.empty(0, dtype=_native.WIDE_HIT)
+        info = dict(nl=len(eng.wide_fetch(_native.WIDE_DICT_LEFT)), nr=len(eng.wide_fetch(_native.WIDE_DICT_RIGHT)),
+                    ng=len(eng.wide_fetch(_native.WIDE_GROUPS)))
+    return KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R), info
+
+
+@pytest.mark.parametrize("geo,length,filt", [((25, 1, 2), 4_000_000, True), ((12, 4, 12), 2_000_000, True),
+                                             ((9, 16, 7), 1_000_000, True), ((14, 0, 14), 2_000_000, False)])
+def test_wide_path_equals_the_packed_path_where_both_apply(geo, length, filt):
+    """kr_wide_run (dictionary composite keys, three sorts) and the one-key path are different
+    programs for the same definition: on geometries both can carry, at a size no text oracle
+    reaches, they must produce the same groups, members, counts and order."""
+    from krisp_amd import amplicon, synth
+    fam = synth.family(11, 2, 2, length, records=7, mu=0.004, snp_every=3000, n_frac=0.001, lower_frac=0.01)
+    a = _groups_packed(fam, *geo, filt)
+    b, info = _groups_wide(fam, *geo, filt)
+    la, lb = amplicon.merged_lines(a), amplicon.merged_lines(b)
+    assert len(la) > 0
+    assert la == lb
+    assert info["ng"] >= len(b) and info["nl"] > 0 and info["nr"] > 0
+
+
+def test_wide_run_at_scale_properties():
+    """4 x 20 Mbp, 30/40/30: every group holds every genome, groups ascend, every hit's window
+    re-read from the text carries its group's flanks; a second run returns the same hits."""
+    from krisp_amd import _native, amplicon, synth
+    L, D, R = 30, 40, 30
+    fam = synth.family(12, 2, 2, 20_000_000, records=16, mu=0.002, snp_every=5000)
+    g1, info = _groups_wide(fam, L, D, R, True)
+    g2, _ = _groups_wide(fam, L, D, R, True)
+    l1 = amplicon.merged_lines(g1)
+    assert l1 == amplicon.merged_lines(g2) and len(g1) > 100
+    names = {nm for nm, _, _ in fam}
+    ingroup = {nm for nm, f, _ in fam if f}
+    pairs = []
+    for g in g1:
+        assert {lab for a in g for lab in a.labels} == names
+        assert len({(a.left, a.right) for a in g}) == 1 and all(len(a.diag) == D for a in g)
+        assert amplicon.ingroup_unique_columns(g, ingroup)
+        pairs.append((g[0].left, g[0].right))
+    assert pairs == sorted(pairs) and len(set(pairs)) == len(pairs)
+    assert info["ng"] >= len(g1)
