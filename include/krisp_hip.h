@@ -74,7 +74,7 @@ enum { KR_SOFT_MAP = 0,    /* lower case -> upper case (krisp_fasta default, kri
 /* stages with device timers (kr_stage_ms) */
 enum { KR_ST_PACK = 0, KR_ST_HIST8, KR_ST_REDUCE8, KR_ST_SCATTER1, KR_ST_HIST2, KR_ST_SCAN2, KR_ST_SCATTER2,
        KR_ST_CHUNKS, KR_ST_LOCALSORT, KR_ST_FALLBACK, KR_ST_INTERSECT, KR_ST_COMPACT, KR_ST_COLLECT,
-       KR_ST_MERGE, KR_ST_COUNT };   /* one kernel per stage (CHUNKS / COMPACT: two tiny ones) */
+       KR_ST_MERGE, KR_ST_LOCATE, KR_ST_COUNT };   /* one kernel per stage (CHUNKS / COMPACT: two tiny ones) */
 
 kr_ctx*     kr_create(int device, size_t hbm_budget_bytes);   /* budget 0 = no limit */
 void        kr_destroy(kr_ctx*);

@@ -20,13 +20,14 @@ WIDE_MAX_K = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
-          "fallback", "intersect", "compact", "collect", "merge"]
+          "fallback", "intersect", "compact", "collect", "merge", "locate"]
 # stage -> the kernel(s) it times (names as rocprofv3 prints them)
 STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1",
                  "hist2": "k_hist2", "scan2": "k_scan2", "scatter2": "k_scatter2",
                  "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort",
                  "fallback": "k_bitonic_stage", "intersect": "k_intersect", "compact": "k_scan+k_gather_cands",
-                 "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact"}
+                 "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact",
+                 "locate": "k_wide_locate"}
 
 # every symbol include/krisp_hip.h declares: (name, restype, argtypes)
 _c = ctypes
@@ -180,11 +181,28 @@ class Engine:
         self._check(self.lib.kr_genome_free(self.ctx, gid), "kr_genome_free")
 
     # ---- intersection
+    MAX_GENOMES_PER_CALL = 32      # MAXG of kr_intersect
+
     def intersect(self, gids, is_ingroup, apply_filter=True):
         ids = np.asarray(gids, dtype=np.int32)
         flags = np.asarray([1 if f else 0 for f in is_ingroup], dtype=np.uint8)
-        return self._check(self.lib.kr_intersect(self.ctx, _ptr(ids), len(ids), _ptr(flags),
-                                                 1 if apply_filter else 0), "kr_intersect")
+        m = self.MAX_GENOMES_PER_CALL
+        if len(ids) <= m:
+            return self._check(self.lib.kr_intersect(self.ctx, _ptr(ids), len(ids), _ptr(flags),
+                                                     1 if apply_filter else 0), "kr_intersect")
+        # cascade: batches of MAXG genomes, candidate lists merged on the device (masks OR-ed);
+        # the filter needs every genome's masks, so it runs once at the end
+        prev = None
+        for o in range(0, len(ids), m):
+            bi, bf = np.ascontiguousarray(ids[o:o + m]), np.ascontiguousarray(flags[o:o + m])
+            n = self._check(self.lib.kr_intersect(self.ctx, _ptr(bi), len(bi), _ptr(bf), 0), "kr_intersect")
+            if prev is not None:
+                n = self.merge_cands(prev, apply_filter=False)
+            if o + m < len(ids):
+                prev = self.cands().copy()
+        if apply_filter:
+            n = self.merge_cands(None, apply_filter=True)
+        return n
 
     def cands(self):
         n = self._check(self.lib.kr_cands_count(self.ctx), "kr_cands_count")

@@ -52,6 +52,10 @@ struct Geom {
     int wibL, wibR; // index bits of the dictionaries (idx[top ib bits] = lower bound)
     const u64 *wdictL, *wdictR;
     const u32 *widxL, *widxR;
+    // mode 2: the composite keys of a genome are generated once per phase (4 dictionary lookups
+    // per window) and kept for the other passes / slices: wcache[2 * pos + strand], ~0 = none
+    u64* wcache;
+    int wcmode;     // 0 no cache, 1 generate + store, 2 load
 };
 
 // absolute key -> relative key of the current slice; false when the key is not in the slice
@@ -180,27 +184,42 @@ __device__ __forceinline__ bool dict_rank(const u64* __restrict__ dict, const u3
 // reverse key present
 __device__ __forceinline__ u32 wide_keys(const u64* __restrict__ codes, const u32* __restrict__ bad, u64 pos,
                                          const Geom& g, u64& kf, u64& kr) {
-    if (!range_valid(bad, pos, g.wk)) return 0;
     if (g.wmode == 1) {
+        if (!range_valid(bad, pos, g.wk)) return 0;
         const int sh = 64 - 2 * g.wlen;
         kf = (read32(codes, pos + g.wfo) >> sh) << sh;
         kr = revcomp32(read32(codes, pos + g.wro)) << sh;
         return 3;
     }
-    const int shL = 64 - 2 * g.wL, shR = 64 - 2 * g.wR;
-    const u64 head = read32(codes, pos);
-    u32 m = 0, a, b;
-    // forward strand: left = first wL bases, right = last wR bases
-    if (dict_rank(g.wdictL, g.widxL, g.wibL, (head >> shL) << shL, a) &&
-        dict_rank(g.wdictR, g.widxR, g.wibR, (read32(codes, pos + g.wk - g.wR) >> shR) << shR, b)) {
-        kf = ((u64)a << g.wshL) | ((u64)b << g.wshR);
-        m |= 1;
+    if (g.wcmode == 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g.wcache + 2 * pos);
+        kf = v.x;
+        kr = v.y;
+        return (kf != ~0ull ? 1u : 0u) | (kr != ~0ull ? 2u : 0u);
     }
-    // reverse strand: left = rc(last wL bases), right = rc(first wR bases)
-    if (dict_rank(g.wdictL, g.widxL, g.wibL, revcomp32(read32(codes, pos + g.wk - g.wL)) << shL, a) &&
-        dict_rank(g.wdictR, g.widxR, g.wibR, revcomp32(head) << shR, b)) {
-        kr = ((u64)a << g.wshL) | ((u64)b << g.wshR);
-        m |= 2;
+    u32 m = 0;
+    if (range_valid(bad, pos, g.wk)) {
+        const int shL = 64 - 2 * g.wL, shR = 64 - 2 * g.wR;
+        const u64 head = read32(codes, pos);
+        u32 a, b;
+        // forward strand: left = first wL bases, right = last wR bases
+        if (dict_rank(g.wdictL, g.widxL, g.wibL, (head >> shL) << shL, a) &&
+            dict_rank(g.wdictR, g.widxR, g.wibR, (read32(codes, pos + g.wk - g.wR) >> shR) << shR, b)) {
+            kf = ((u64)a << g.wshL) | ((u64)b << g.wshR);
+            m |= 1;
+        }
+        // reverse strand: left = rc(last wL bases), right = rc(first wR bases)
+        if (dict_rank(g.wdictL, g.widxL, g.wibL, revcomp32(read32(codes, pos + g.wk - g.wL)) << shL, a) &&
+            dict_rank(g.wdictR, g.widxR, g.wibR, revcomp32(head) << shR, b)) {
+            kr = ((u64)a << g.wshL) | ((u64)b << g.wshR);
+            m |= 2;
+        }
+    }
+    if (g.wcmode == 1) {
+        ulonglong2 v;
+        v.x = (m & 1) ? kf : ~0ull;      // (rank(left) < 2^bits - 1: a composite key is never all ones)
+        v.y = (m & 2) ? kr : ~0ull;
+        *reinterpret_cast<ulonglong2*>(g.wcache + 2 * pos) = v;
     }
     return m;
 }
@@ -1389,6 +1408,34 @@ __global__ void k_cands_compact(const kr_cand* __restrict__ cur, u32 n, const u3
 // ----------------------------------------------------------------------------
 typedef struct { u32 cand, genome, pos, strand; } wide_hit;
 
+// idx[b] = lower bound of bucket b (top ib bits) in a sorted key array, idx[2^ib] = n.
+// (1) entry i fills the buckets (bucket(i - 1), bucket(i)] -- at most the 32 nearest, the
+// array was preset to WIDE_UNSET; (2) a bucket still unset (inside a long empty run, or past
+// the last key) does its own binary search.  Streaming passes for evenly spread keys.
+#define WIDE_UNSET 0xFFFFFFFFu
+__global__ void k_index_sorted(const u64* __restrict__ keys, u32 n, int ib, u32* __restrict__ idx) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 hi = keys[i] >> (64 - ib);
+    u64 lo = i == 0 ? 0 : (keys[i - 1] >> (64 - ib)) + 1;
+    if (hi >= 32 && lo < hi - 31) lo = hi - 31;
+    for (u64 b = lo; b <= hi; b++) idx[b] = (u32)i;
+}
+__global__ void k_index_fill(const u64* __restrict__ keys, u32 n, int ib, u32* __restrict__ idx) {
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 nbk = 1ull << ib;
+    if (b > nbk) return;
+    if (b == nbk) { idx[b] = n; return; }
+    if (idx[b] != WIDE_UNSET) return;
+    const u64 target = b << (64 - ib);
+    u32 l = 0, r = n;
+    while (l < r) {
+        const u32 mid = l + ((r - l) >> 1);
+        if (keys[mid] < target) l = mid + 1; else r = mid;
+    }
+    idx[b] = l;
+}
+
 __global__ void k_cand_prefixes(const kr_cand* __restrict__ cands, u32 n, u64* __restrict__ out) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = cands[i].prefix;
@@ -1398,25 +1445,26 @@ __device__ __forceinline__ u32 code_at(const u64* __restrict__ codes, u64 p) {
     return (u32)(codes[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3u;
 }
 
-// pass A (hitoff == nullptr): masks[(cand * 2 + side) * W + col / 16] |= 1 << (4 * (col % 16) + base), cnt[cand]++
-// pass B: hits[hitoff[cand] + cursor[cand]++] for the candidates the filter kept
+// per member window: masks[(cand * 2 + side) * W + col / 16] |= 1 << (4 * (col % 16) + base),
+// cnt[cand]++, and the window's group is remembered: ci[2 * pos + strand] (WIDE_NONE = no group)
+#define WIDE_NONE 0xFFFFFFFFu
 __global__ __launch_bounds__(256) void k_wide_locate(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                     u64 npos, Geom g, const u64* __restrict__ fin,
                                                     const u32* __restrict__ fidx, int fib, int D, int W, u32 side,
-                                                    u32 gidx, u64* __restrict__ masks, u32* __restrict__ cnt,
-                                                    const u32* __restrict__ hitoff, u32* __restrict__ cursor,
-                                                    wide_hit* __restrict__ hits) {
+                                                    u64* __restrict__ masks, u32* __restrict__ cnt,
+                                                    uint2* cibuf, u32 cistride) {
     u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; pos < npos; pos += stride) {
-        if (bad[pos >> 5] == 0xFFFFFFFFu) continue;
-        u64 key[2];
-        const u32 m = wide_keys(codes, bad, pos, g, key[0], key[1]);
-        for (u32 strand = 0; strand < 2; strand++) {
-            if (!((m >> strand) & 1)) continue;
-            u32 ci;
-            if (!dict_rank(fin, fidx, fib, key[strand], ci)) continue;
-            if (hitoff == nullptr) {
+        uint2 found = make_uint2(WIDE_NONE, WIDE_NONE);
+        if (bad[pos >> 5] != 0xFFFFFFFFu) {
+            u64 key[2];
+            const u32 m = wide_keys(codes, bad, pos, g, key[0], key[1]);
+            for (u32 strand = 0; strand < 2; strand++) {
+                if (!((m >> strand) & 1)) continue;
+                u32 ci;
+                if (!dict_rank(fin, fidx, fib, key[strand], ci)) continue;
+                if (strand) found.y = ci; else found.x = ci;
                 atomicAdd(&cnt[ci], 1u);
                 u64* mrow = masks + ((u64)ci * 2 + side) * W;
                 u64 acc = 0;
@@ -1429,14 +1477,57 @@ __global__ __launch_bounds__(256) void k_wide_locate(const u64* __restrict__ cod
                         acc = 0;
                     }
                 }
-            } else {
-                const u32 o = hitoff[ci];
-                if (hitoff[ci + 1] == o) continue;
-                const u32 slot = o + atomicAdd(&cursor[ci], 1u);
-                hits[slot] = wide_hit{ci, gidx, (u32)pos, strand};
             }
         }
+        cibuf[pos * cistride] = found;     // (may alias this window's entry of g.wcache, read above)
     }
+}
+
+// hits[hitoff[cand] + cursor[cand]++] for the member windows of the groups the filter kept
+__global__ __launch_bounds__(256) void k_wide_emit(const uint2* __restrict__ cibuf, u32 cistride, u64 npos, u32 gidx,
+                                                  const u32* __restrict__ hitoff, u32* __restrict__ cursor,
+                                                  wide_hit* __restrict__ hits) {
+    u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; pos < npos; pos += stride) {
+        const uint2 f = cibuf[pos * cistride];
+#pragma unroll
+        for (u32 strand = 0; strand < 2; strand++) {
+            const u32 ci = strand ? f.y : f.x;
+            if (ci == WIDE_NONE) continue;
+            const u32 o = hitoff[ci];
+            if (hitoff[ci + 1] == o) continue;
+            hits[o + atomicAdd(&cursor[ci], 1u)] = wide_hit{ci, gidx, (u32)pos, strand};
+        }
+    }
+}
+
+// exclusive scan of a long u32 array in tiles of 2048: tile sums -> k_scan of the sums -> apply
+__global__ __launch_bounds__(256) void k_tile_sums(const u32* __restrict__ in, u32 n, u32* __restrict__ tsum) {
+    __shared__ u32 waves[17];
+    const u32 base = blockIdx.x * 2048u + threadIdx.x * 8u;
+    u32 sum = 0;
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) sum += base + q < n ? in[base + q] : 0u;
+    u32 total;
+    (void)block_excl_scan(sum, waves, total);
+    if (threadIdx.x == 0) tsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void k_tile_apply(const u32* __restrict__ in, u32 n, const u32* __restrict__ tpos,
+                                                   u32 ntiles, u32* __restrict__ out) {
+    __shared__ u32 waves[17];
+    const u32 base = blockIdx.x * 2048u + threadIdx.x * 8u;
+    u32 v[8], sum = 0;
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) { v[q] = base + q < n ? in[base + q] : 0u; sum += v[q]; }
+    u32 total;
+    u32 ex = block_excl_scan(sum, waves, total) + tpos[blockIdx.x];
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) {
+        if (base + q < n) out[base + q] = ex;
+        ex += v[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tpos[ntiles];
 }
 
 // keep a candidate when some diagnostic column separates the groups (or no filter is asked)
@@ -1472,7 +1563,7 @@ struct Genome {
     size_t n_bases = 0;
     u64 nwords = 0;          // ceil(n/32)
     u64 nmax = 0;            // sum of the slice counts
-    DevBuf bases;
+    DevBuf bases, wkeys;     // wkeys: wide path, this genome's composite keys (then its windows' groups)
     std::vector<Slice> sl;
     bool uploaded = false, sorted = false, finalized = false;
     int64_t count = -1;
@@ -1484,7 +1575,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     bool pending = false;
-    DevBuf codes, bad, partial8, base1, tmpkeys, tp, tiledesc, tilehist;
+    DevBuf codes, bad, partial8, base1, tmpkeys, tp, tiledesc, tilehist, wkeys;
 };
 #define MAX_LANES 8
 
@@ -1520,7 +1611,8 @@ struct kr_ctx {
     struct Wide {
         bool on = false;
         int L = 0, D = 0, R = 0, k = 0, omit = 0, W = 0;
-        DevBuf dict[2], idx[2], fin, fidx, masks, cnt, hitoff, cursor, hits;
+        DevBuf dict[2], idx[2], fin, fidx, masks, cnt, hitoff, cursor, hits, cibuf, tsum, tpos;
+        bool genome_cache = false;
         u32 ndict[2] = {0, 0}, nfin = 0;
         int ib[2] = {1, 1}, fib = 1;
         int64_t nhits = -1;
@@ -1595,6 +1687,7 @@ static void release(kr_ctx* c, DevBuf& b) {
 
 static void release_genome(kr_ctx* c, Genome& G) {
     release(c, G.bases);
+    release(c, G.wkeys);
     for (Slice& S : G.sl) {
         release(c, S.keys);
         release(c, S.off);
@@ -1710,7 +1803,7 @@ void kr_destroy(kr_ctx* c) {
     resolve_stages(c);
     for (int i = 0; i < c->nlanes; i++) {
         Lane& ln = c->lanes[i];
-        DevBuf* lb[] = {&ln.codes, &ln.bad, &ln.partial8, &ln.base1, &ln.tmpkeys, &ln.tp, &ln.tiledesc, &ln.tilehist};
+        DevBuf* lb[] = {&ln.codes, &ln.bad, &ln.partial8, &ln.base1, &ln.tmpkeys, &ln.tp, &ln.tiledesc, &ln.tilehist, &ln.wkeys};
         for (DevBuf* b : lb) release(c, *b);
     }
     for (auto& kv : c->genomes) release_genome(c, kv.second);
@@ -1719,7 +1812,7 @@ void kr_destroy(kr_ctx* c) {
     for (DevBuf* b : all) release(c, *b);
     {
         auto& w = c->wide;
-        DevBuf* wb[] = {&w.dict[0], &w.dict[1], &w.idx[0], &w.idx[1], &w.fin, &w.fidx, &w.masks, &w.cnt, &w.hitoff, &w.cursor, &w.hits};
+        DevBuf* wb[] = {&w.dict[0], &w.dict[1], &w.idx[0], &w.idx[1], &w.fin, &w.fidx, &w.masks, &w.cnt, &w.hitoff, &w.cursor, &w.hits, &w.cibuf, &w.tsum, &w.tpos};
         for (DevBuf* b : wb) release(c, *b);
     }
     for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -1898,8 +1991,12 @@ static int count_slices(kr_ctx* c, Genome& G) {
     G.sorted = G.finalized = false;
     G.count = -1;
     for (int s = 0; s < c->nslices; s++) {
-        const Geom gs = slice_geom(c, (u32)s);
-        launch_hist8(c, G, ln, st, gs);
+        Geom gs = slice_geom(c, (u32)s);
+        if (gs.wmode == 2 && gs.wcache) gs.wcmode = s == 0 ? 1 : 2;
+        {
+            StageScope sc(c, KR_ST_HIST8, st);
+            launch_hist8(c, G, ln, st, gs);
+        }
         hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
         HIPCHK(c, hipMemcpyAsync(tot.data(), (u32*)ln.base1.p + 260, 256 * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -1940,7 +2037,13 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
     return KR_OK;
 }
 
-int kr_genome_sort(kr_ctx* c, int id) {
+static int genome_sort(kr_ctx* c, int id, bool reuse_count);
+int kr_genome_sort(kr_ctx* c, int id) { return genome_sort(c, id, false); }
+
+// reuse_count: count_slices(G) has just run on this lane (single slice, single lane): the
+// codes, the bad bits and the workgroup histograms (already prefix-summed by k_reduce8a) are
+// still in the lane's scratch
+static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
     if (!c) return KR_ERR_PARAM;
     auto it = c->genomes.find(id);
     if (it == c->genomes.end() || !it->second.uploaded) return fail(c, KR_ERR_STATE, "genome %d not uploaded", id);
@@ -1956,15 +2059,18 @@ int kr_genome_sort(kr_ctx* c, int id) {
     u32* bad = (u32*)ln.bad.p;
     G.sorted = G.finalized = false;
     G.count = -1;
-    {
+    const bool cached_keys = reuse_count && c->nlanes == 1 && c->g.wmode == 2 && c->g.wcache;
+    reuse_count = reuse_count && c->nslices == 1 && c->nlanes == 1;
+    if (!reuse_count) {
         StageScope sc(c, KR_ST_PACK, st);
         launch_pack(c, G, ln, st);
     }
     for (int s = 0; s < c->nslices; s++) {
         Slice& S = G.sl[s];
-        const Geom g = slice_geom(c, (u32)s);
+        Geom g = slice_geom(c, (u32)s);
+        if (cached_keys) g.wcmode = 2;
         S.count = -1;
-        {
+        if (!reuse_count) {
             StageScope sc(c, KR_ST_HIST8, st);
             launch_hist8(c, G, ln, st, g);
         }
@@ -1972,7 +2078,8 @@ int kr_genome_sort(kr_ctx* c, int id) {
             StageScope sc(c, KR_ST_REDUCE8, st);
             if (g.b > 8)
                 HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(S.nmax / P2_TILE) + 257) * 8, st));
-            hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+            if (!reuse_count)
+                hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
             hipLaunchKernelGGL(k_reduce8b, dim3(1), dim3(1024), 0, st, (const u32*)ln.base1.p + 260,
                                (u32*)ln.base1.p, (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
         }
@@ -2285,7 +2392,10 @@ int64_t kr_intersect(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int
             HIPCHK(c, hipMemcpyAsync(&total, (u32*)c->chunkpos.p + AS.nchunks, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             HIPCHK(c, hipGetLastError());
-            if ((rc = ensure_keep(c, c->candB, (running + total + 2) * sizeof(kr_cand), running * sizeof(kr_cand))))
+            size_t want = running + total + 2;
+            if (s == 0 && c->nslices > 1)       // size for all slices at once instead of doubling through them
+                want = (size_t)((double)total * c->nslices * 1.15) + 4096;
+            if ((rc = ensure_keep(c, c->candB, want * sizeof(kr_cand), running * sizeof(kr_cand))))
                 return rc;
             if (total)
                 hipLaunchKernelGGL(k_gather_cands, dim3(AS.nchunks), dim3(64), 0, st, g.sbits, g.slice,
@@ -2421,22 +2531,43 @@ static int64_t wide_phase(kr_ctx* c, const int* ids, int n, const uint8_t* is_in
     int rc;
     for (int i = 0; i < n; i++) {
         Genome& G = c->genomes[ids[i]];
+        if (c->g.wmode == 2 && c->wide.genome_cache) {
+            if ((rc = ensure(c, G.wkeys, (G.nwords + PAD_WORDS) * 32 * 16))) return rc;
+            c->g.wcache = (u64*)G.wkeys.p;
+        }
         if ((rc = count_slices(c, G))) return rc;
-        if ((rc = kr_genome_sort(c, ids[i]))) return rc;
+        if ((rc = genome_sort(c, ids[i], true))) return rc;
     }
-    int64_t nc = kr_intersect(c, ids, n, is_in, 0);
-    if (nc < 0) return nc;
+    // more than MAXG genomes: cascade (the running candidate list goes through the host)
+    int64_t nc = -1;
+    std::vector<kr_cand> prev;
+    for (int o = 0; o < n; o += MAXG) {
+        const int m = std::min(MAXG, n - o);
+        nc = kr_intersect(c, ids + o, m, is_in + o, 0);
+        if (nc < 0) return nc;
+        if (o > 0) {
+            nc = kr_cands_merge(c, prev.data(), prev.size(), 1, 0);
+            if (nc < 0) return nc;
+        }
+        if (o + MAXG < n) {
+            prev.resize((size_t)nc);
+            if (nc) HIPCHK(c, hipMemcpy(prev.data(), c->candB.p, (size_t)nc * sizeof(kr_cand), hipMemcpyDeviceToHost));
+        }
+    }
     if (nc >= (1ll << 32) - 1) return fail(c, KR_ERR_CAPACITY, "wide path: %lld dictionary entries (>= 2^32)", (long long)nc);
-    ib = std::max(1, std::min(std::min(22, keybits), ceil_log2((u64)nc + 1) - 2));
+    ib = std::max(1, std::min(std::min(27, keybits), ceil_log2((u64)nc + 1)));     // ~1 entry per index bucket
     if ((rc = ensure(c, out, ((size_t)nc + 2) * 8))) return rc;
     if ((rc = ensure(c, idx, (((size_t)1 << ib) + 2) * 4))) return rc;
     hipStream_t st = c->stream;
     if (nc)
         hipLaunchKernelGGL(k_cand_prefixes, dim3(((u32)nc + 255) / 256), dim3(256), 0, st, (const kr_cand*)c->candB.p,
                            (u32)nc, (u64*)out.p);
-    const u32 nbk = 1u << ib;
-    hipLaunchKernelGGL(k_offsets_from_sorted, dim3((nbk + 1 + 255) / 256), dim3(256), 0, st, (const u64*)out.p, (u32)nc,
-                       nbk, 64 - ib, (u32*)idx.p);
+    HIPCHK(c, hipMemsetAsync(idx.p, 0xFF, (((size_t)1 << ib) + 1) * 4, st));
+    if (nc)
+        hipLaunchKernelGGL(k_index_sorted, dim3((u32)(((u64)nc + 255) / 256)), dim3(256), 0, st, (const u64*)out.p,
+                           (u32)nc, ib, (u32*)idx.p);
+    hipLaunchKernelGGL(k_index_fill, dim3((u32)((((u64)1 << ib) + 1 + 255) / 256)), dim3(256), 0, st,
+                       (const u64*)out.p, (u32)nc, ib, (u32*)idx.p);
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     return nc;
@@ -2444,7 +2575,7 @@ static int64_t wide_phase(kr_ctx* c, const int* ids, int n, const uint8_t* is_in
 
 int64_t kr_wide_run(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int apply_filter) {
     if (!c || !c->wide.on) return fail(c, KR_ERR_STATE, "kr_set_params_wide first");
-    if (n < 1 || n > MAXG) return fail(c, KR_ERR_PARAM, "kr_wide_run: 1 .. %d genomes per call", MAXG);
+    if (n < 1) return fail(c, KR_ERR_PARAM, "kr_wide_run: need at least one genome");
     for (int i = 0; i < n; i++) {
         auto it = c->genomes.find(ids[i]);
         if (it == c->genomes.end() || !it->second.uploaded) return fail(c, KR_ERR_STATE, "genome %d not uploaded", ids[i]);
@@ -2471,7 +2602,7 @@ int64_t kr_wide_run(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int 
     }
     // phase 3: composite keys rank(left) : rank(right)
     {
-        int bitsL = std::max(1, ceil_log2(w.ndict[0])), bitsR = std::max(1, ceil_log2(w.ndict[1]));
+        int bitsL = std::max(1, ceil_log2((u64)w.ndict[0] + 1)), bitsR = std::max(1, ceil_log2(w.ndict[1]));
         if ((bitsL + bitsR) & 1) bitsR++;
         while (bitsL + bitsR < 2 * sb + 2) bitsR += 2;       // room for the slice digits
         const int half = (bitsL + bitsR) / 2;
@@ -2488,6 +2619,21 @@ int64_t kr_wide_run(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int 
         g.wdictR = (const u64*)w.dict[1].p;
         g.widxL = (const u32*)w.idx[0].p;
         g.widxR = (const u32*)w.idx[1].p;
+        // composite keys are generated once per genome and phase (16 bytes per window start).
+        // Kept per genome when that fits comfortably -- the locate pass then reads them too and
+        // leaves each window's group in their place -- else in one lane buffer (sort passes only)
+        w.genome_cache = false;
+        if (c->nlanes == 1) {
+            size_t need = 0, fr = 0, tot = 0;
+            for (int i = 0; i < n; i++) need += (c->genomes[ids[i]].nwords + PAD_WORDS) * 32 * 16;
+            if (getenv("KR_WIDE_CACHE")) w.genome_cache = atoi(getenv("KR_WIDE_CACHE")) != 0;
+            else w.genome_cache = hipMemGetInfo(&fr, &tot) == hipSuccess && need <= fr / 6;
+            if (!w.genome_cache) {
+                int rcw = ensure(c, c->lanes[0].wkeys, ((c->max_bases + 31) / 32 + PAD_WORDS) * 32 * 16);
+                if (rcw) return rcw;
+                g.wcache = (u64*)c->lanes[0].wkeys.p;
+            }
+        }
         c->g = g;
         int64_t nf = wide_phase(c, ids, n, is_in, w.fin, w.fidx, w.fib, bitsL + bitsR);
         if (nf < 0) return nf;
@@ -2498,6 +2644,27 @@ int64_t kr_wide_run(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int 
     int rc;
     const u32 nf = w.nfin;
     const int W = std::max(1, w.W);
+    {
+        // the sorted composite keys are not needed any more: give their memory back when the
+        // locate buffers would not fit beside them
+        size_t need = (size_t)nf * 2 * W * 8 + 3 * ((size_t)nf + 4) * 4, fr = 0, tot = 0;
+        if (!w.genome_cache)
+            for (int i = 0; i < n; i++) need += c->genomes[ids[i]].n_bases * sizeof(uint2);
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > fr / 10 * 8) {
+            HIPCHK(c, hipDeviceSynchronize());
+            for (int i = 0; i < n; i++) {
+                Genome& G = c->genomes[ids[i]];
+                for (Slice& S : G.sl) {
+                    release(c, S.keys); release(c, S.off); release(c, S.chunkstart); release(c, S.chunkdesc); release(c, S.ovf);
+                }
+                G.sl.clear();
+                G.sorted = G.finalized = false;
+            }
+            release(c, c->candA);
+            release(c, c->candB);
+            c->ncand = -1;
+        }
+    }
     if ((rc = ensure(c, w.masks, (size_t)nf * 2 * W * 8))) return rc;
     if ((rc = ensure(c, w.cnt, ((size_t)nf + 4) * 4))) return rc;
     if ((rc = ensure(c, w.hitoff, ((size_t)nf + 4) * 4))) return rc;
@@ -2508,30 +2675,54 @@ int64_t kr_wide_run(kr_ctx* c, const int* ids, int n, const uint8_t* is_in, int 
     HIPCHK(c, hipMemsetAsync(w.cnt.p, 0, ((size_t)nf + 4) * 4, st));
     HIPCHK(c, hipMemsetAsync(w.cursor.p, 0, ((size_t)nf + 4) * 4, st));
     Lane& ln = c->lanes[0];
-    for (int pass = 0; pass < 2; pass++) {
-        for (int i = 0; i < n; i++) {
-            Genome& G = c->genomes[ids[i]];
-            if (G.n_bases == 0) continue;
-            launch_pack(c, G, ln, st);
-            const u32 grid = (u32)std::min<u64>((G.n_bases + 255) / 256, 16384);
-            hipLaunchKernelGGL(k_wide_locate, dim3(grid), dim3(256), 0, st, (const u64*)ln.codes.p,
-                               (const u32*)ln.bad.p, (u64)G.n_bases, c->g, (const u64*)w.fin.p, (const u32*)w.fidx.p,
-                               w.fib, w.D, W, is_in[i] ? 0u : 1u, (u32)i, (u64*)w.masks.p, (u32*)w.cnt.p,
-                               pass ? (const u32*)w.hitoff.p : (const u32*)nullptr, (u32*)w.cursor.p,
-                               (wide_hit*)w.hits.p);
+    // the group of every window of every genome (8 bytes per base): written by the locate pass,
+    // streamed by the emit pass once the filter has decided
+    std::vector<u64> cioff(n + 1, 0);
+    for (int i = 0; i < n; i++) cioff[i + 1] = cioff[i] + c->genomes[ids[i]].n_bases;
+    if (!w.genome_cache && (rc = ensure(c, w.cibuf, (cioff[n] + 2) * sizeof(uint2)))) return rc;
+    for (int i = 0; i < n; i++) {
+        Genome& G = c->genomes[ids[i]];
+        if (G.n_bases == 0) continue;
+        launch_pack(c, G, ln, st);
+        const u32 grid = (u32)std::min<u64>((G.n_bases + 255) / 256, 16384);
+        Geom g = c->g;
+        g.wcmode = 0;
+        uint2* ci = (uint2*)w.cibuf.p + cioff[i];
+        if (w.genome_cache) {
+            g.wcache = (u64*)G.wkeys.p;
+            g.wcmode = 2;
+            ci = (uint2*)G.wkeys.p;
         }
-        if (pass == 0) {
-            hipLaunchKernelGGL(k_wide_filter, dim3((nf + 255) / 256), dim3(256), 0, st, (const u64*)w.masks.p,
-                               (u32*)w.cnt.p, nf, w.D, W, apply_filter ? 1 : 0);
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)w.cnt.p, (u32*)w.hitoff.p, nf);
-            u32 total = 0;
-            HIPCHK(c, hipMemcpyAsync(&total, (u32*)w.hitoff.p + nf, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            HIPCHK(c, hipGetLastError());
-            w.nhits = total;
-            if (total == 0) return 0;
-            if ((rc = ensure(c, w.hits, ((size_t)total + 2) * sizeof(wide_hit)))) return rc;
-        }
+        StageScope sc(c, KR_ST_LOCATE, st);
+        hipLaunchKernelGGL(k_wide_locate, dim3(grid), dim3(256), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
+                           (u64)G.n_bases, g, (const u64*)w.fin.p, (const u32*)w.fidx.p, w.fib, w.D, W,
+                           is_in[i] ? 0u : 1u, (u64*)w.masks.p, (u32*)w.cnt.p, ci, w.genome_cache ? 2u : 1u);
+    }
+    hipLaunchKernelGGL(k_wide_filter, dim3((nf + 255) / 256), dim3(256), 0, st, (const u64*)w.masks.p, (u32*)w.cnt.p,
+                       nf, w.D, W, apply_filter ? 1 : 0);
+    {
+        const u32 ntiles = (nf + 2047) / 2048;
+        if ((rc = ensure(c, w.tsum, ((size_t)ntiles + 4) * 4))) return rc;
+        if ((rc = ensure(c, w.tpos, ((size_t)ntiles + 4) * 4))) return rc;
+        hipLaunchKernelGGL(k_tile_sums, dim3(ntiles), dim3(256), 0, st, (const u32*)w.cnt.p, nf, (u32*)w.tsum.p);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const u32*)w.tsum.p, (u32*)w.tpos.p, ntiles);
+        hipLaunchKernelGGL(k_tile_apply, dim3(ntiles), dim3(256), 0, st, (const u32*)w.cnt.p, nf, (const u32*)w.tpos.p,
+                           ntiles, (u32*)w.hitoff.p);
+    }
+    u32 total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, (u32*)w.hitoff.p + nf, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    w.nhits = total;
+    if (total == 0) return 0;
+    if ((rc = ensure(c, w.hits, ((size_t)total + 2) * sizeof(wide_hit)))) return rc;
+    for (int i = 0; i < n; i++) {
+        Genome& G = c->genomes[ids[i]];
+        if (G.n_bases == 0) continue;
+        const u32 grid = (u32)std::min<u64>((G.n_bases + 255) / 256, 16384);
+        const uint2* ci = w.genome_cache ? (const uint2*)G.wkeys.p : (const uint2*)w.cibuf.p + cioff[i];
+        hipLaunchKernelGGL(k_wide_emit, dim3(grid), dim3(256), 0, st, ci, w.genome_cache ? 2u : 1u, (u64)G.n_bases,
+                           (u32)i, (const u32*)w.hitoff.p, (u32*)w.cursor.p, (wide_hit*)w.hits.p);
     }
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());

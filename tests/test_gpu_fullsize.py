@@ -130,14 +130,18 @@ def _groups_wide(fam, L, D, R, do_filter):
     return KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R), info
 
 
-@pytest.mark.parametrize("geo,length,filt", [((25, 1, 2), 4_000_000, True), ((12, 4, 12), 2_000_000, True),
-                                             ((9, 16, 7), 1_000_000, True), ((14, 0, 14), 2_000_000, False)])
-def test_wide_path_equals_the_packed_path_where_both_apply(geo, length, filt):
+@pytest.mark.parametrize("geo,length,filt,sb", [((25, 1, 2), 4_000_000, True, None), ((12, 4, 12), 2_000_000, True, None),
+                                                ((9, 16, 7), 1_000_000, True, None), ((14, 0, 14), 2_000_000, False, None),
+                                                ((25, 1, 2), 3_000_000, True, 1), ((10, 6, 12), 1_000_000, True, 2)])
+def test_wide_path_equals_the_packed_path_where_both_apply(geo, length, filt, sb, monkeypatch):
     """kr_wide_run (dictionary composite keys, three sorts) and the one-key path are different
     programs for the same definition: on geometries both can carry, at a size no text oracle
     reaches, they must produce the same groups, members, counts and order."""
     from krisp_amd import amplicon, synth
     fam = synth.family(11, 2, 2, length, records=7, mu=0.004, snp_every=3000, n_frac=0.001, lower_frac=0.01)
+    if sb is not None:
+        monkeypatch.setenv("KR_SLICE_BASES", str(sb))       # both paths sort in 4^sb key-space slices
+        monkeypatch.setenv("KR_WIDE_CACHE", "0")            # and the locate pass re-generates its keys
     a = _groups_packed(fam, *geo, filt)
     b, info = _groups_wide(fam, *geo, filt)
     la, lb = amplicon.merged_lines(a), amplicon.merged_lines(b)

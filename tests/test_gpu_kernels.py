@@ -161,6 +161,38 @@ def test_intersect_and_collect(N, K, L, D, R, length, n):
             assert np.array_equal(got["out_mask"], want_f["out_mask"])
 
 
+def test_more_genomes_than_one_intersect_call_takes(N, K):
+    """40 genomes (kr_intersect takes 32): the cascade over batches equals the oracle's n-way
+    intersection, on the one-key path and on the wide path"""
+    from krisp_amd import amplicon, synth
+    from krisp_amd import krisp_fasta as KF
+    L, D, R = 9, 1, 4
+    fam = synth.family(5, 25, 15, 30_000, records=2, mu=0.0005, snp_every=400)
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
+    want = K.intersect(want_keys, flags, L, D, R, apply_filter=True)
+    assert len(want) > 5
+    with N.Engine() as e:
+        e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            e.add(i, t)
+        assert e.intersect(ids, flags, apply_filter=True) == len(want)
+        got = e.cands()
+        for f in ("prefix", "in_mask", "out_mask"):
+            assert np.array_equal(got[f], want[f])
+        recs = e.collect(ids)
+        packed = amplicon.groups_from_records(recs, [nm for nm, _, _ in fam], L, D, R)
+    with N.Engine() as e:
+        e.set_params_wide(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            e.upload(i, t)
+        assert e.wide_run(ids, flags, apply_filter=True) > 0
+        hits = e.wide_fetch(N.WIDE_HITS)
+    wide = KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R)
+    assert amplicon.merged_lines(wide) == amplicon.merged_lines(packed)
+
+
 def test_stage_timers_and_medium_size(N, K):
     fam = _family(77, 4, 1_000_000)
     flags = [f for _, f, _ in fam]

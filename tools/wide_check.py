@@ -17,7 +17,9 @@ def main():
         eng.set_params_wide(L, D, R, max_bases=max(len(t) for _, _, t in fam))
         for i, (_, _, t) in enumerate(fam):
             eng.upload(i, t)
+        eng.stage_enable(True)
         for rep in range(3):
+            eng.stage_reset()
             eng.sync()
             t0 = time.time()
             n = eng.wide_run(ids, [f for _, f, _ in fam], apply_filter=True)
@@ -26,6 +28,7 @@ def main():
             info = [len(eng.wide_fetch(w)) for w in (0, 1, 2)]
             print(f"run {rep}: {dt * 1e3:.1f} ms, hits {n}, dictL {info[0]}, dictR {info[1]}, groups {info[2]}, "
                   f"{2 * sum(len(t) for _, _, t in fam) / dt / 1e9:.2f} G windows/s", flush=True)
+            print("   ", {k: (round(v[0], 1), v[1]) for k, v in eng.stage_times().items() if v[1]}, flush=True)
         print(eng.debug_info())
 
 
