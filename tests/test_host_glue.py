@@ -250,3 +250,68 @@ def test_library_ingest_matches_the_python_reader(tmp_path):
             p = str(tmp_path / f"r{i}{ext}")
             (gzip.open if ext.endswith(".gz") else open)(p, "wb").write(text.encode())
             check(p)
+
+
+def _brute_wide_hits(texts, flags, L, D, R, omit, do_filter):
+    """Pure-Python statement of what kr_wide_run returns (test-side, tiny inputs): member
+    windows of the (left,right) groups present in every genome that pass the filter."""
+    k = L + D + R
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    wins = []            # (genome, pos, strand, left, diag, right)
+    for gi, t in enumerate(texts):
+        s = bytes(t).decode()
+        for pos in range(len(s) - k + 1):
+            w = s[pos:pos + k]
+            if "\n" in w:
+                continue
+            if omit and not w.isupper():
+                continue
+            w = w.upper()
+            if not set(w) <= set("ACGT"):
+                continue
+            rc = "".join(comp[c] for c in reversed(w))
+            for strand, x in ((0, w), (1, rc)):
+                wins.append((gi, pos, strand, x[:L], x[L:L + D], x[L + D:]))
+    by = {}
+    for gi, pos, strand, l, d, r in wins:
+        by.setdefault((l, r), []).append((gi, pos, strand, d))
+    groups = sorted(p for p, m in by.items() if {x[0] for x in m} == set(range(len(texts))))
+    hits = []
+    for ci, p in enumerate(groups):
+        m = by[p]
+        if do_filter:
+            keep = False
+            for col in range(D):
+                a = {x[3][col] for x in m if flags[x[0]]}
+                b = {x[3][col] for x in m if not flags[x[0]]}
+                keep = keep or not (a & b)
+            if not keep:
+                continue
+        hits += [(ci, gi, pos, strand) for gi, pos, strand, _ in m]
+    return np.array(hits, dtype=_native.WIDE_HIT) if hits else np.empty(0, dtype=_native.WIDE_HIT)
+
+
+WIDE_RAND = [c for c in FC if c["name"].startswith("rand") and c["L"] + c["D"] + c["R"] > 32 and "csv" in c]
+
+
+@pytest.mark.parametrize("case", WIDE_RAND, ids=[c["name"] for c in WIDE_RAND])
+def test_render_from_wide_hits_matches_reference_text(case, tmp_path):
+    """host glue of the wide path: hits (here from the brute-force statement above) -> groups
+    -> the reference's final text, on the golden cases with amplicons longer than 32"""
+    L, D, R = case["L"], case["D"], case["R"]
+    paths = _paths(case, tmp_path)
+    files = case["ingroup"] + case["outgroup"]
+    texts = [fasta.to_bases(fasta.read_records(paths[fn])) for fn in files]
+    labels = [KF.simplename(f) for f in files]
+    ing = frozenset(KF.simplename(f) for f in case["ingroup"])
+    flags = [lab in ing for lab in labels]
+    hits = _brute_wide_hits(texts, flags, L, D, R, case["omit_soft"], D > 0)
+    np.random.default_rng(0).shuffle(hits)                 # the device returns them unordered inside a group
+    hits = hits[np.argsort(hits["cand"], kind="stable")]
+    groups = KF._groups_from_hits(hits, texts, labels, L, D, R)
+    ingroup = [KF.simplename(f) for f in case["ingroup"]] if case["outgroup"] else None
+    csv, align = amplicon.render(groups, ingroup, dot=case["dot"])
+    assert csv == case["csv"]
+    assert align == case["align"]
+    want = case["filtered_canon"] if "filtered_canon" in case else case["merged_canon"]
+    assert sorted(amplicon.merged_lines(groups)) == want

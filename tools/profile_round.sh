@@ -1,0 +1,28 @@
+#!/bin/bash
+# Regenerates the measurement artefacts of one round on the GPU box (run through gpurun from the
+# repo root):  bash tools/profile_round.sh r01
+#   profiles/<round>/bench.json          the bench line (default workload = BASELINE configs[1])
+#   profiles/<round>/kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
+#   profiles/traffic.json                HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE)
+# Everything is written under gpurun_out/<round>/ (merged back by gpurun); copy into profiles/ afterwards.
+set -e
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$R
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -1 "$OUT/bench.json"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-stage-timers > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-stage-timers > "$OUT/pmc_write.log" 2>&1
+cd "$ROOT"
+find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
+F=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1)
+W=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
+python3 profiles/make_traffic.py "$F" "$W" "$OUT/traffic.json"
+# the raw per-dispatch csv files are large: keep the summaries only
+rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
+find "$OUT/stats" -type f ! -name "*kernel_stats.csv" -delete
+ls -la "$OUT"
