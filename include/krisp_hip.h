@@ -170,6 +170,9 @@ int64_t kr_stage_launches(kr_ctx*, int stage);
 int64_t kr_debug_fetch(kr_ctx*, int genome_id, int what, void* out, size_t cap_bytes);
 /* property check for sizes no oracle reaches: adjacent key pairs out of order (0 = sorted) */
 int64_t kr_debug_inversions(kr_ctx*, int genome_id);
+/* timing aid: k_localsort re-run `reps` times over a sorted genome; mode 0 = as shipped,
+ * 64 = load + store only, 128 = without the ranking step.  Average ms per launch. */
+double  kr_debug_localsort(kr_ctx*, int genome_id, int reps, int mode);
 int     kr_debug_info(kr_ctx*, int64_t* out8);  /* b, nbuckets, T, CAP, nwg, overflow segments, fallback launches, 0 */
 
 #ifdef __cplusplus

@@ -64,6 +64,7 @@ SYMBOLS = [
     ("kr_stage_launches", _c.c_int64, [_P, _c.c_int]),
     ("kr_debug_fetch", _c.c_int64, [_P, _c.c_int, _c.c_int, _P, _c.c_size_t]),
     ("kr_debug_inversions", _c.c_int64, [_P, _c.c_int]),
+    ("kr_debug_localsort", _c.c_double, [_P, _c.c_int, _c.c_int, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
 ]
 

@@ -787,7 +787,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
             e = ls;
             m = e - s;
         }
-        if (m > 0) {
+        if (m > 0 && (dbg & 64)) {          // kr_debug_localsort: stream the chunk through, nothing else
+#pragma unroll
+            for (int i = 0; i < (int)LS_PER; i++) {
+                u32 p = tid + i * LS_THREADS;
+                if (p < m) keys[s + p] = key[i];
+            }
+        } else if (m > 0) {
             const u32 nbk = hi - lo;
             const int clog = nbk <= 1 ? 0 : 32 - __clz((int)(nbk - 1));
             const int sh = rb + clog - LS_NB_LOG;
@@ -837,7 +843,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
                 if (p < m) S[cnt16_get(cnt, sub[i]) + r[i]] = key[i];
             }
             __syncthreads();
-            if (s_maxbin <= LS_BIN_LIMIT) {
+            if (dbg & 128) {                // kr_debug_localsort: binned but not ranked
+                for (u32 p = tid; p < m; p += LS_THREADS) keys[s + p] = S[p];
+            } else if (s_maxbin <= LS_BIN_LIMIT) {
+                // keys are walked in PLACED order: lanes of a wave rank neighbours, so their LDS reads
+                // are adjacent and their global stores fall into one or two 512-byte runs.  (Measured,
+                // tools/ls_ablate.py: load + store alone 0.34 ms per 10^8 keys, binning adds nothing,
+                // this step 0.17 ms; staging the ranked keys through LDS for fully coalesced stores,
+                // fewer barriers and unconditional neighbour reads were all A/B-tested: no gain.)
 #pragma unroll 2
                 for (int i = 0; i < (int)LS_PER; i++) {
                     u32 p = tid + i * LS_THREADS;
@@ -2747,6 +2760,38 @@ int64_t kr_wide_fetch(kr_ctx* c, int what, void* out, size_t cap_bytes) {
     HIPCHK(c, hipDeviceSynchronize());
     if (n) HIPCHK(c, hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost));
     return (int64_t)n;
+}
+
+// timing aid (tools/ls_ablate.py): run k_localsort `reps` times over the (already sorted) slice 0
+// of a genome; mode 0 = the kernel as it is, 64 = load + store only, 128 = without the ranking
+// step.  A final regular pass restores the order.  Returns the average milliseconds per launch.
+double kr_debug_localsort(kr_ctx* c, int id, int reps, int mode) {
+    if (!c) return -1.0;
+    auto it = c->genomes.find(id);
+    if (it == c->genomes.end() || !it->second.sorted || it->second.sl.empty()) return -1.0;
+    if (finalize(c, {&it->second})) return -1.0;
+    Slice& S = it->second.sl[0];
+    hipStream_t st = c->stream;
+    const u32 grid = std::min<u32>(S.nchunks, (u32)c->ls_grid);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, st);
+    for (int r = 0; r < reps; r++)
+        hipLaunchKernelGGL(k_localsort, dim3(grid), dim3(LS_THREADS), 0, st, (u64*)S.keys.p, (const u32*)S.off.p,
+                           (const uint4*)S.chunkdesc.p, S.nchunks, c->g.b, (u32*)S.ovf.p,
+                           (uint4*)((char*)S.ovf.p + 16), mode);
+    (void)hipEventRecord(b, st);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    hipLaunchKernelGGL(k_localsort, dim3(grid), dim3(LS_THREADS), 0, st, (u64*)S.keys.p, (const u32*)S.off.p,
+                       (const uint4*)S.chunkdesc.p, S.nchunks, c->g.b, (u32*)S.ovf.p,
+                       (uint4*)((char*)S.ovf.p + 16), 0);
+    (void)hipStreamSynchronize(st);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return reps > 0 ? (double)ms / reps : 0.0;
 }
 
 int kr_sync(kr_ctx* c) {
