@@ -43,7 +43,7 @@ STAGE_BYTES = {
 }
 
 
-def make_genomes(config, rank, world, per_rank, length, independent=False):
+def make_genomes(config, rank, world, per_rank, length, independent=False, masked=False):
     from krisp_amd import synth
     anc = None if independent else synth.ancestor(config, length)
     out = []
@@ -53,7 +53,9 @@ def make_genomes(config, rank, world, per_rank, length, independent=False):
         ing = (g % per_rank) < per_rank // 2
         codes = synth.genome_codes(config, g, length, ing, mu=0.01, snp_every=10000,
                                    independent=independent, anc=anc)
-        out.append((g, ing, synth.codes_to_text(codes, records=16)))
+        # --masked = SURVEY 8(d) secondary variant (ii): 0.1 % of the bases N in 1 kb runs, 5 % lower case
+        out.append((g, ing, synth.codes_to_text(codes, records=16, n_frac=0.001 if masked else 0.0,
+                                                lower_frac=0.05 if masked else 0.0, seed=100 * config + g)))
     return out
 
 
@@ -92,6 +94,7 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=4, help="genomes per GPU")
     ap.add_argument("--ldr", type=int, nargs=3, default=[25, 1, 2])
     ap.add_argument("--independent", action="store_true", help="independent random genomes")
+    ap.add_argument("--masked", action="store_true", help="0.1 %% N in 1 kb runs + 5 %% lower case (soft-mask mapped)")
     ap.add_argument("--cpu-length", type=int, default=0,
                     help="bases per genome of the CPU baseline sample (0 = calibrate to ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,7 +125,7 @@ def main():
 
     L, D, R = args.ldr
     config = 2
-    genomes = make_genomes(config, rank, world, args.per_gpu, args.length, args.independent)
+    genomes = make_genomes(config, rank, world, args.per_gpu, args.length, args.independent, args.masked)
     eng = _native.Engine(device=local_rank)
     eng.set_params(L, D, R, omit_soft=False, max_bases=max(len(t) for _, _, t in genomes))
     ids = []
@@ -160,6 +163,7 @@ def main():
     dt = time.perf_counter() - t0
     stages = eng.stage_times() if not args.no_stage_timers else {}
     kmers_local = sum(eng.count(g) for g in ids)
+    copy_gbps = eng.copy_gbps(1 << 30, 10) if rank == 0 else None      # measured streaming-copy peak of this box
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -197,6 +201,7 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(achieved / copy_gbps, 4),
                     "bytes_per_kmer": STAGE_BYTES[dom], "kmers_per_launch": per_launch,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                     "pipeline_model_GBps": round(MODEL_BYTES_PER_KMER * value / world / 1e9, 1),
@@ -209,7 +214,10 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {args.per_gpu} synthetic {args.length / 1e6:g} Mbp random "
                                    f"genomes per GPU (half in / half out over the {args.per_gpu * world}-genome "
-                                   f"family, mu=0.01, planted SNP / 10 kb), {L}/{D}/{R} spacer search",
+                                   f"family, mu=0.01, planted SNP / 10 kb"
+                                   + (", independent genomes" if args.independent else "")
+                                   + (", 0.1 % N runs + 5 % lower case" if args.masked else "")
+                                   + f"), {L}/{D}/{R} spacer search",
                        "kmers_per_step": kmers_total, "candidates": int(ncand),
                        "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else " + tree-reduce of candidates")},
             "roofline": roof,

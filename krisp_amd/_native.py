@@ -65,6 +65,7 @@ SYMBOLS = [
     ("kr_debug_fetch", _c.c_int64, [_P, _c.c_int, _c.c_int, _P, _c.c_size_t]),
     ("kr_debug_inversions", _c.c_int64, [_P, _c.c_int]),
     ("kr_debug_localsort", _c.c_double, [_P, _c.c_int, _c.c_int, _c.c_int]),
+    ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
 ]
 
@@ -279,6 +280,12 @@ class Engine:
         self.lib.kr_debug_info(self.ctx, _ptr(o))
         return dict(b=int(o[0]), nbuckets=int(o[1]), T=int(o[2]), CAP=int(o[3]), nwg=int(o[4]),
                     overflow_segments=int(o[5]), fallback_launches=int(o[6]), nslices=int(o[7]))
+
+    def copy_gbps(self, nbytes=1 << 30, reps=10):
+        v = self.lib.kr_debug_copy_gbps(self.ctx, nbytes, reps)
+        if v < 0:
+            raise KrispHipError("kr_debug_copy_gbps failed")
+        return v
 
     def inversions(self, gid):
         return self._check(self.lib.kr_debug_inversions(self.ctx, gid), "kr_debug_inversions")

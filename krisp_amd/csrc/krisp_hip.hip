@@ -76,6 +76,9 @@ __device__ __forceinline__ bool slice_key(u64& key, const Geom& g) {
 #ifndef P1_WORDS
 #define P1_WORDS 64        // code words per pass-1 tile (2048 positions, <= 4096 keys)
 #endif
+#ifndef P1_OCC
+#define P1_OCC 3           // waves per SIMD k_scatter1 is compiled for (= resident workgroups per CU at 256 threads)
+#endif
 #define P1_TPW (P1_T / P1_WORDS)        // threads per code word
 #define P1_PPT (32 / P1_TPW)            // window positions per thread
 #define P1_KPT (2 * P1_PPT)             // keys per thread per tile: positions x 2 strands
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(1024) void k_scan(const u32* __restrict__ in, u32* 
 // digit counts, stage the keys digit-sorted in LDS, copy the runs out.
 // ----------------------------------------------------------------------------
 template <int WIDE>
-__global__ __launch_bounds__(P1_T) void k_scatter1(const u64* __restrict__ codes, const u32* __restrict__ bad,
+__global__ __launch_bounds__(P1_T, P1_OCC) void k_scatter1(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                   u64 nwords, const u32* __restrict__ base1,
                                                   const u32* __restrict__ rowoff, u64* __restrict__ dst, Geom g) {
     __shared__ __attribute__((aligned(16))) u64 stage[P1_STAGE];
@@ -1554,6 +1557,13 @@ __global__ void k_wide_filter(const u64* __restrict__ masks, u32* __restrict__ c
         keep = ((x >> (4 * (col & 15))) & 15ull) == 0;
     }
     if (!keep) cnt[i] = 0;
+}
+
+// plain streaming copy (the measured-peak companion of the 8 TB/s spec figure in bench.py)
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, u64 n16) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 static thread_local std::string g_last_error;
@@ -2792,6 +2802,34 @@ double kr_debug_localsort(kr_ctx* c, int id, int reps, int mode) {
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     return reps > 0 ? (double)ms / reps : 0.0;
+}
+
+// measured HBM copy rate on this device: GB/s of read + write traffic of a streaming copy kernel
+double kr_debug_copy_gbps(kr_ctx* c, size_t bytes, int reps) {
+    if (!c || bytes < 4096 || reps < 1) return -1.0;
+    if (hipSetDevice(c->device) != hipSuccess) return -1.0;
+    DevBuf a, b;
+    if (ensure(c, a, bytes) || ensure(c, b, bytes)) { release(c, a); release(c, b); return -1.0; }
+    hipStream_t st = c->stream;
+    (void)hipMemsetAsync(a.p, 1, bytes, st);
+    (void)hipMemsetAsync(b.p, 2, bytes, st);
+    const u64 n16 = bytes / 16;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_copy16, dim3(8192), dim3(256), 0, st, (const uint4*)a.p, (uint4*)b.p, n16);   // warm-up
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps; r++)
+        hipLaunchKernelGGL(k_copy16, dim3(8192), dim3(256), 0, st, (const uint4*)a.p, (uint4*)b.p, n16);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    release(c, a);
+    release(c, b);
+    return ms > 0 ? 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9 : -1.0;
 }
 
 int kr_sync(kr_ctx* c) {
