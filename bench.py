@@ -185,9 +185,16 @@ def main():
             dom = max(cand, key=lambda s: cand[s][0])
             ms, launches = cand[dom]
             avg_ms = ms / launches
-            # hist launches once per sweep, intersect once per step over all local genomes
-            per_launch = kmers_local if dom == "intersect" else kmers_local / len(ids)
-            achieved = STAGE_BYTES[dom] * per_launch / (avg_ms * 1e-3) / 1e9
+            # k-mers through one launch: per genome (and key-space slice) for the sort stages, all local
+            # genomes (per slice) for the intersect.  Sliced genomes (> 4.2e8 keys) take one more pass:
+            # their pass 0 writes all keys once (0.19 + 8 B), every slice's pass 1 reads and writes them
+            nslices = eng.debug_info()["nslices"]
+            stage_bytes = dict(STAGE_BYTES)
+            if nslices > 1:
+                stage_bytes["scatter1"] = 0.1875 + 8.0 + 16.0
+                stage_bytes["hist8"] = 0.1875 + 8.0
+            per_launch = kmers_local * args.steps / launches
+            achieved = stage_bytes[dom] * kmers_local * args.steps / (ms * 1e-3) / 1e9
             # HBM bytes per launch of the same kernel from the PMC counters (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE passes of this command, profiles/make_traffic.py), valid for
             # the default workload only; expressed like `achieved`: bytes per launch / launch time
@@ -202,7 +209,7 @@ def main():
             roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(achieved / copy_gbps, 4),
-                    "bytes_per_kmer": STAGE_BYTES[dom], "kmers_per_launch": per_launch,
+                    "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                     "pipeline_model_GBps": round(MODEL_BYTES_PER_KMER * value / world / 1e9, 1),
                     "pipeline_model_frac": round(MODEL_BYTES_PER_KMER * value / world / 1e9 / HBM_PEAK_GBPS, 4),

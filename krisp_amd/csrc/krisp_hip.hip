@@ -480,14 +480,15 @@ __global__ __launch_bounds__(1024) void k_scan(const u32* __restrict__ in, u32* 
 template <int WIDE>
 __global__ __launch_bounds__(P1_T, P1_OCC) void k_scatter1(const u64* __restrict__ codes, const u32* __restrict__ bad,
                                                   u64 nwords, const u32* __restrict__ base1,
+                                                  const u64* __restrict__ base64,
                                                   const u32* __restrict__ rowoff, u64* __restrict__ dst, Geom g) {
     __shared__ __attribute__((aligned(16))) u64 stage[P1_STAGE];
-    __shared__ u32 cur[256];
+    __shared__ u64 cur[256];      // (64 bit: the slice pre-partition of a >= 2 Gbp genome exceeds 2^32 keys)
     __shared__ u32 cnt[256];
-    __shared__ u32 delta[256];
+    __shared__ u64 delta[256];
     __shared__ u32 waves[17];
     const u32 tid = threadIdx.x;
-    if (tid < 256) cur[tid] = base1[tid] + rowoff[(u64)blockIdx.x * 256 + tid];
+    if (tid < 256) cur[tid] = (base64 ? base64[tid] : (u64)base1[tid]) + rowoff[(u64)blockIdx.x * 256 + tid];
     u64 wpw = (nwords + NWG - 1) / NWG;
     u64 w0 = (u64)blockIdx.x * wpw;
     u64 w1 = w0 + wpw < nwords ? w0 + wpw : nwords;
@@ -521,6 +522,85 @@ __global__ __launch_bounds__(P1_T, P1_OCC) void k_scatter1(const u64* __restrict
                     }
                 }
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P1_KPT; q++)
+            if ((vm >> q) & 1) r[q] = atomicAdd(&cnt[(u32)(key[q] >> 56)], 1u);
+        __syncthreads();
+        u32 c = tid < 256 ? cnt[tid] : 0, total;
+        u32 ex = block_excl_scan(c, waves, total);
+        if (tid < 256) {
+            cnt[tid] = ex;
+            delta[tid] = cur[tid] - ex;
+            cur[tid] += c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P1_KPT; q++)
+            if ((vm >> q) & 1) stage[cnt[(u32)(key[q] >> 56)] + r[q]] = key[q];
+        __syncthreads();
+        for (u32 p = tid; p < total; p += P1_T) {
+            u64 k2 = stage[p];
+            dst[p + delta[(u32)(k2 >> 56)]] = k2;
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K3k  sliced genomes: "pass 0" partitions ALL keys of a genome once by their top byte
+// (k_hist8 / k_scatter1 on absolute keys, 64-bit bucket bases from k_bases64) -- a slice is a
+// run of 2^(8 - sbits) such buckets, i.e. one contiguous region -- and every slice then takes
+// its pass 1 from that region instead of regenerating all windows of the genome:
+// k_hist8k / k_scatter1k = k_hist8 / k_scatter1 with keys read (and made relative) instead of
+// generated.  Same workgroup ranges in both, so the private cursors stay exact.
+// ----------------------------------------------------------------------------
+__global__ void k_bases64(const u32* __restrict__ tot, u64* __restrict__ base64) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        u64 run = 0;
+        for (int d = 0; d < 256; d++) { base64[d] = run; run += tot[d]; }
+        base64[256] = run;
+    }
+}
+
+#define P1K_TILE (P1_T * P1_KPT)      // keys per tile of the from-keys kernels (= P1_STAGE)
+
+__global__ __launch_bounds__(P1_T) void k_hist8k(const u64* __restrict__ src, u64 n, int sbits,
+                                                u32* __restrict__ partial8) {
+    __shared__ u32 lhist[256];
+    if (threadIdx.x < 256) lhist[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 per = ((n + NWG - 1) / NWG + P1K_TILE - 1) / P1K_TILE * P1K_TILE;
+    const u64 k0 = (u64)blockIdx.x * per;
+    const u64 k1 = k0 + per < n ? k0 + per : n;
+    for (u64 i = k0 + threadIdx.x; i < k1; i += P1_T) atomicAdd(&lhist[(u32)((src[i] << sbits) >> 56)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 256) partial8[(u64)blockIdx.x * 256 + threadIdx.x] = lhist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(P1_T) void k_scatter1k(const u64* __restrict__ src, u64 n, int sbits,
+                                                   const u32* __restrict__ base1, const u32* __restrict__ rowoff,
+                                                   u64* __restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) u64 stage[P1_STAGE];
+    __shared__ u32 cur[256];
+    __shared__ u32 cnt[256];
+    __shared__ u32 delta[256];
+    __shared__ u32 waves[17];
+    const u32 tid = threadIdx.x;
+    if (tid < 256) cur[tid] = base1[tid] + rowoff[(u64)blockIdx.x * 256 + tid];
+    const u64 per = ((n + NWG - 1) / NWG + P1K_TILE - 1) / P1K_TILE * P1K_TILE;
+    const u64 k0 = (u64)blockIdx.x * per;
+    const u64 k1 = k0 + per < n ? k0 + per : n;
+    for (u64 t0 = k0; t0 < k1; t0 += P1K_TILE) {
+        u64 key[P1_KPT];
+        u32 r[P1_KPT];
+        u32 vm = 0;
+        if (tid < 256) cnt[tid] = 0;
+#pragma unroll
+        for (int q = 0; q < P1_KPT; q++) {
+            const u64 i = t0 + (u64)q * P1_T + tid;
+            if (i < k1) { key[q] = src[i] << sbits; vm |= 1u << q; }
         }
         __syncthreads();
 #pragma unroll
@@ -1599,6 +1679,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     bool pending = false;
     DevBuf codes, bad, partial8, base1, tmpkeys, tp, tiledesc, tilehist, wkeys;
+    DevBuf pass0, base64;    // sliced genomes: all keys partitioned by their top byte, the 64-bit bucket bases
 };
 #define MAX_LANES 8
 
@@ -1826,7 +1907,8 @@ void kr_destroy(kr_ctx* c) {
     resolve_stages(c);
     for (int i = 0; i < c->nlanes; i++) {
         Lane& ln = c->lanes[i];
-        DevBuf* lb[] = {&ln.codes, &ln.bad, &ln.partial8, &ln.base1, &ln.tmpkeys, &ln.tp, &ln.tiledesc, &ln.tilehist, &ln.wkeys};
+        DevBuf* lb[] = {&ln.codes, &ln.bad, &ln.partial8, &ln.base1, &ln.tmpkeys, &ln.tp, &ln.tiledesc, &ln.tilehist, &ln.wkeys,
+                        &ln.pass0, &ln.base64};
         for (DevBuf* b : lb) release(c, *b);
     }
     for (auto& kv : c->genomes) release_genome(c, kv.second);
@@ -1885,6 +1967,10 @@ static int plan_sort(kr_ctx* c, size_t max_bases, int Lmin, int& sb, int& b) {
     const u64 nmax = 2 * (u64)max_bases;
     sb = 0;
     while (sb < 4 && (nmax >> (2 * sb)) > (BUCKET_AVG << 18)) sb++;
+    // once slices are needed, finer ones pay: a slice of <= 1e8 keys sorts with fan-out 2^16, whose
+    // pass-2 runs are 256 bytes instead of 64 (C5: 33.0 -> 36.4 G k-mers/s with 64 instead of 16 slices)
+    if (sb > 0)
+        while (sb < 4 && sb < Lmin && (nmax >> (2 * sb)) > (BUCKET_AVG << 16)) sb++;
     if (const char* e = getenv("KR_SLICE_BASES")) sb = std::max(0, std::min(4, atoi(e)));
     if (sb > Lmin) {
         if (getenv("KR_SLICE_BASES")) sb = Lmin;
@@ -1972,6 +2058,7 @@ static int ensure_lanes(kr_ctx* c, u64 maxcount) {
         if ((rc = ensure(c, ln.base1, (260 + 256) * 4))) return rc;     // bases[257] | column totals[256]
         if ((rc = ensure(c, ln.tmpkeys, (maxcount + 2) * 8))) return rc;
         if ((rc = ensure(c, ln.tp, 260 * 4))) return rc;
+        if ((rc = ensure(c, ln.base64, 260 * 8))) return rc;
         if ((rc = ensure(c, ln.tiledesc, ntmax * 8))) return rc;
         if ((rc = ensure(c, ln.tilehist, ntmax * (nb >> 8) * 4))) return rc;
     }
@@ -2013,18 +2100,22 @@ static int count_slices(kr_ctx* c, Genome& G) {
     G.nmax = 0;
     G.sorted = G.finalized = false;
     G.count = -1;
+    // ONE histogram of the top byte of the absolute keys: a slice is 2^(8 - sbits) of its buckets
+    Geom g0 = c->g;
+    g0.sbits = 0;
+    g0.slice = 0;
+    if (g0.wmode == 2 && g0.wcache) g0.wcmode = 1;
+    {
+        StageScope sc(c, KR_ST_HIST8, st);
+        launch_hist8(c, G, ln, st, g0);
+    }
+    hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+    HIPCHK(c, hipMemcpyAsync(tot.data(), (u32*)ln.base1.p + 260, 256 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int per = 256 >> c->g.sbits;          // buckets per slice
     for (int s = 0; s < c->nslices; s++) {
-        Geom gs = slice_geom(c, (u32)s);
-        if (gs.wmode == 2 && gs.wcache) gs.wcmode = s == 0 ? 1 : 2;
-        {
-            StageScope sc(c, KR_ST_HIST8, st);
-            launch_hist8(c, G, ln, st, gs);
-        }
-        hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
-        HIPCHK(c, hipMemcpyAsync(tot.data(), (u32*)ln.base1.p + 260, 256 * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
         u64 cnt = 0;
-        for (u32 v : tot) cnt += v;
+        for (int d = s * per; d < (s + 1) * per; d++) cnt += tot[d];
         if (cnt >= (1ull << 31))
             return fail(c, KR_ERR_CAPACITY, "slice %d of genome %d holds %llu keys (>= 2^31): raise KR_SLICE_BASES", s,
                         G.id, (unsigned long long)cnt);
@@ -2032,6 +2123,9 @@ static int count_slices(kr_ctx* c, Genome& G) {
         G.nmax += cnt;
         maxcount = std::max(maxcount, cnt);
     }
+    if (c->nslices > 1)
+        for (int i = 0; i < c->nlanes; i++)
+            if ((rc = ensure(c, c->lanes[i].pass0, (G.nmax + 2) * 8))) return rc;
     HIPCHK(c, hipGetLastError());
     return ensure_lanes(c, maxcount);
 }
@@ -2063,9 +2157,9 @@ int kr_genome_upload(kr_ctx* c, int id, const uint8_t* bases, size_t n) {
 static int genome_sort(kr_ctx* c, int id, bool reuse_count);
 int kr_genome_sort(kr_ctx* c, int id) { return genome_sort(c, id, false); }
 
-// reuse_count: count_slices(G) has just run on this lane (single slice, single lane): the
-// codes, the bad bits and the workgroup histograms (already prefix-summed by k_reduce8a) are
-// still in the lane's scratch
+// reuse_count: count_slices(G) has just run on this lane (single lane): the codes, the bad
+// bits and the workgroup histograms of the absolute top byte (already prefix-summed by
+// k_reduce8a) are still in the lane's scratch
 static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
     if (!c) return KR_ERR_PARAM;
     auto it = c->genomes.find(id);
@@ -2083,17 +2177,54 @@ static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
     G.sorted = G.finalized = false;
     G.count = -1;
     const bool cached_keys = reuse_count && c->nlanes == 1 && c->g.wmode == 2 && c->g.wcache;
-    reuse_count = reuse_count && c->nslices == 1 && c->nlanes == 1;
+    reuse_count = reuse_count && c->nlanes == 1;
+    const bool sliced = c->nslices > 1;
     if (!reuse_count) {
         StageScope sc(c, KR_ST_PACK, st);
         launch_pack(c, G, ln, st);
     }
+    if (sliced) {
+        // pass 0: all keys of the genome, generated once, partitioned by their top byte; slice s
+        // is the contiguous run of its 2^(8 - sbits) buckets
+        if (ln.pass0.bytes < (G.nmax + 2) * 8) return fail(c, KR_ERR_STATE, "genome %d: slice plan is stale", id);
+        Geom g0 = c->g;
+        g0.sbits = 0;
+        g0.slice = 0;
+        if (!reuse_count) {
+            if (g0.wmode == 2 && g0.wcache && c->nlanes == 1) g0.wcmode = 1;
+            StageScope sc(c, KR_ST_HIST8, st);
+            launch_hist8(c, G, ln, st, g0);
+        }
+        {
+            StageScope sc(c, KR_ST_REDUCE8, st);
+            if (!reuse_count)
+                hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
+            hipLaunchKernelGGL(k_bases64, dim3(1), dim3(64), 0, st, (const u32*)ln.base1.p + 260, (u64*)ln.base64.p);
+        }
+        g0.wcmode = (g0.wmode == 2 && g0.wcache && c->nlanes == 1) ? 2 : 0;
+        (void)cached_keys;
+        StageScope sc(c, KR_ST_SCATTER1, st);
+        if (g0.wmode)
+            hipLaunchKernelGGL(k_scatter1<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                               (const u32*)nullptr, (const u64*)ln.base64.p, (const u32*)ln.partial8.p,
+                               (u64*)ln.pass0.p, g0);
+        else
+            hipLaunchKernelGGL(k_scatter1<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
+                               (const u32*)nullptr, (const u64*)ln.base64.p, (const u32*)ln.partial8.p,
+                               (u64*)ln.pass0.p, g0);
+    }
+    u64 region = 0;       // start of the current slice inside the pass-0 array
     for (int s = 0; s < c->nslices; s++) {
         Slice& S = G.sl[s];
         Geom g = slice_geom(c, (u32)s);
         if (cached_keys) g.wcmode = 2;
         S.count = -1;
-        if (!reuse_count) {
+        const u64* src = (const u64*)ln.pass0.p + region;
+        region += S.nmax;
+        if (sliced) {
+            StageScope sc(c, KR_ST_HIST8, st);
+            hipLaunchKernelGGL(k_hist8k, dim3(NWG), dim3(P1_T), 0, st, src, (u64)S.nmax, g.sbits, (u32*)ln.partial8.p);
+        } else if (!reuse_count) {
             StageScope sc(c, KR_ST_HIST8, st);
             launch_hist8(c, G, ln, st, g);
         }
@@ -2101,7 +2232,7 @@ static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
             StageScope sc(c, KR_ST_REDUCE8, st);
             if (g.b > 8)
                 HIPCHK(c, hipMemsetAsync(ln.tiledesc.p, 0, ((size_t)(S.nmax / P2_TILE) + 257) * 8, st));
-            if (!reuse_count)
+            if (sliced || !reuse_count)
                 hipLaunchKernelGGL(k_reduce8a, dim3(256), dim3(256), 0, st, (u32*)ln.partial8.p, (u32*)ln.base1.p + 260);
             hipLaunchKernelGGL(k_reduce8b, dim3(1), dim3(1024), 0, st, (const u32*)ln.base1.p + 260,
                                (u32*)ln.base1.p, (u32*)ln.tp.p, (uint2*)ln.tiledesc.p);
@@ -2109,12 +2240,17 @@ static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
         u64* pass1_dst = g.b > 8 ? (u64*)ln.tmpkeys.p : (u64*)S.keys.p;
         {
             StageScope sc(c, KR_ST_SCATTER1, st);
-            if (g.wmode)
+            if (sliced)
+                hipLaunchKernelGGL(k_scatter1k, dim3(NWG), dim3(P1_T), 0, st, src, (u64)S.nmax, g.sbits,
+                                   (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst);
+            else if (g.wmode)
                 hipLaunchKernelGGL(k_scatter1<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad,
-                                   G.nwords, (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
+                                   G.nwords, (const u32*)ln.base1.p, (const u64*)nullptr, (const u32*)ln.partial8.p,
+                                   pass1_dst, g);
             else
                 hipLaunchKernelGGL(k_scatter1<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad,
-                                   G.nwords, (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst, g);
+                                   G.nwords, (const u32*)ln.base1.p, (const u64*)nullptr, (const u32*)ln.partial8.p,
+                                   pass1_dst, g);
         }
         if (g.b > 8) {
             const u32 ntmax = (u32)(S.nmax / P2_TILE) + 257;

@@ -113,6 +113,12 @@ def test_key_space_slices_report(N):
         e.set_params(25, 1, 2, max_bases=1000)
         want = 4 ** int(os.environ.get("KR_SLICE_BASES", "0"))
         assert e.debug_info()["nslices"] == want
+    if "KR_SLICE_BASES" not in os.environ:
+        # the size policy: one sort unit up to 4.2e8 keys, then slices of <= 1.05e8 keys
+        for bases, want in ((50_000_000, 1), (200_000_000, 1), (500_000_000, 16), (3_000_000_000, 64)):
+            with N.Engine() as e:
+                e.set_params(25, 1, 2, max_bases=bases)
+                assert e.debug_info()["nslices"] == want, bases
 
 
 def _family(seed, n, length, mu=0.01):
