@@ -160,6 +160,10 @@ double  kr_timer_end_ms(kr_ctx*);                              /* syncs */
 /* accumulated device time of one stage since the last kr_stage_reset (syncs);
  * only collected after kr_stage_enable(ctx, 1) (it serialises launches). */
 int     kr_stage_enable(kr_ctx*, int on);
+/* time only the stages whose bit (1 << KR_ST_x) is set: the event pairs around every launch
+ * cost ~4 % of a C2 step when all stages are timed; bench.py times the dominant kernel only
+ * inside its timed region (the full table comes from a calibration pass before it) */
+int     kr_stage_select(kr_ctx*, unsigned stage_mask);
 int     kr_stage_reset(kr_ctx*);
 double  kr_stage_ms(kr_ctx*, int stage);
 int64_t kr_stage_launches(kr_ctx*, int stage);

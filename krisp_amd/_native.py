@@ -59,6 +59,7 @@ SYMBOLS = [
     ("kr_timer_begin", _c.c_int, [_P]),
     ("kr_timer_end_ms", _c.c_double, [_P]),
     ("kr_stage_enable", _c.c_int, [_P, _c.c_int]),
+    ("kr_stage_select", _c.c_int, [_P, _c.c_uint]),
     ("kr_stage_reset", _c.c_int, [_P]),
     ("kr_stage_ms", _c.c_double, [_P, _c.c_int]),
     ("kr_stage_launches", _c.c_int64, [_P, _c.c_int]),
@@ -266,6 +267,13 @@ class Engine:
 
     def stage_enable(self, on=True):
         self.lib.kr_stage_enable(self.ctx, 1 if on else 0)
+
+    def stage_select(self, names):
+        """time only the named stages (event pairs around their launches)"""
+        mask = 0
+        for n in names:
+            mask |= 1 << STAGES.index(n)
+        self.lib.kr_stage_select(self.ctx, mask)
 
     def stage_reset(self):
         self.lib.kr_stage_reset(self.ctx)

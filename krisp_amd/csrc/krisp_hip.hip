@@ -1703,6 +1703,7 @@ struct kr_ctx {
     // timers
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool stage_on = false;
+    unsigned stage_mask = ~0u;      // stages whose launches are bracketed by events while stage_on
     struct Pair { hipEvent_t a, b; int stage; };
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;
@@ -1809,7 +1810,7 @@ struct StageScope {
     hipStream_t stream;
     StageScope(kr_ctx* c_, int st, hipStream_t s_ = nullptr) : c(c_), stage(st), stream(s_ ? s_ : c_->stream) {
         c->stage_n[st]++;
-        if (!c->stage_on) return;
+        if (!c->stage_on || !((c->stage_mask >> st) & 1u)) return;
         auto get = [&]() {
             hipEvent_t e;
             if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); }
@@ -2999,6 +3000,14 @@ double kr_timer_end_ms(kr_ctx* c) {
 int kr_stage_enable(kr_ctx* c, int on) {
     if (!c) return KR_ERR_PARAM;
     c->stage_on = on != 0;
+    c->stage_mask = ~0u;
+    return KR_OK;
+}
+
+int kr_stage_select(kr_ctx* c, unsigned mask) {
+    if (!c) return KR_ERR_PARAM;
+    c->stage_on = mask != 0;
+    c->stage_mask = mask;
     return KR_OK;
 }
 

@@ -22,7 +22,7 @@ for round in 1 2 3; do
     python3 - "$v" "$round" "$ROOT/gpurun_out/ab_$v.$round.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
-st = d["roofline"]["stage_ms_per_step"]
+st = d["roofline"]["stage_ms_per_step_calibration"]
 print(sys.argv[1], "round", sys.argv[2], "ms/step %.3f" % d["ms_per_step"], "G/s %.2f" % (d["value"] / 1e9),
       " ".join(f"{k}={v:.3f}" for k, v in st.items() if v > 0.1))
 PY
