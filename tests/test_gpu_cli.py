@@ -348,3 +348,35 @@ def test_random_genomes_with_iupac_letters_match_the_text_oracle(seed, tmp_path)
     expect = O.filter_lines(merged, [O.simplename(f) for f in ing]) if D > 0 else merged
     groups, _ = KF.find_regions(ing, outg, L, R, k, omit_soft=omit)
     assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
+
+
+@pytest.mark.parametrize("name,texts,n_in", [
+    ("shorter_than_k", [">a\nACGTACGTAC\n", ">b\nACGTACGTACGTTTT\n"], 1),
+    ("all_N", [">a\n" + "N" * 300 + "\n", ">b\n" + "ACGT" * 80 + "\n"], 1),
+    ("single_genome", [">a\n" + "ACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAGCATCGACTAGCTACGACTAGCGACGGCATCGA" * 2 + "\n"], 1),
+    ("identical_genomes", [">a\n" + "ACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAGCATCGACTAGCTACGACTAGCGACGGCATCGA\n"] * 3, 2),
+    ("empty_record_and_blank_lines", [">a\n\n>b\nACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAG\n\n  CATCGACTAGCTACGAC  \n", ">c\nACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAGCATCGACTAGCTACGAC\n"], 1),
+    ("palindromic_repeat", [">a\n" + "ACGT" * 40 + "\n", ">b\n" + "ACGT" * 45 + "\n"], 1),
+])
+def test_wide_path_edge_cases_match_the_text_oracle(name, texts, n_in, tmp_path):
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    from oracle import krisp_oracle as O
+    files = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"g{i}.fa"
+        p.write_text(t)
+        files.append(str(p))
+    ing, outg = files[:n_in], files[n_in:]
+    for L, D, R in ((12, 14, 10), (5, 30, 5), (16, 0, 17)):
+        k = L + D + R
+        sf = [(f"{O.basename(f)}.{k}mers", O.extract_sorted_kmers(f, L, R, k, False)) for f in files]
+        merged = O.merge_tree(sf)
+        expect = O.filter_lines(merged, [O.simplename(f) for f in ing]) if D > 0 else merged
+        if len(files) == 1:
+            # one genome: mergeFiles moves the k-mer file (no labels); the later stages label its
+            # lines 'merged_file' (shared.py:373) and, without an outgroup, keep every group
+            expect = O.groups_to_lines(O.read_groups(merged, "merged_file"))
+        groups, _ = KF.find_regions(ing, outg, L, R, k)
+        got = amplicon.merged_lines(groups)
+        assert sorted(got) == sorted(expect), (name, L, D, R)
