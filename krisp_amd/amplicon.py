@@ -6,7 +6,6 @@ final CSV and alignment text are byte-identical at --cores 1
 outputAlignments.py:26-162).  The diagnostic filter itself runs on the device
 (kr_intersect / kr_cands_merge); nothing here decides which groups survive.
 """
-from collections import Counter
 
 import numpy as np
 
@@ -37,8 +36,17 @@ class Amplicon:
 
     def label_string(self):
         """Amplicon.py:170-187: name or name(count), ';' joined, names sorted."""
-        counts = Counter(self.labels)
-        return ";".join(n if c == 1 else f"{n}({c})" for n, c in sorted(counts.items()))
+        out, prev, run = [], None, 0
+        for lab in self.labels:                 # (sorted: equal names are adjacent)
+            if lab == prev:
+                run += 1
+                continue
+            if prev is not None:
+                out.append(prev if run == 1 else f"{prev}({run})")
+            prev, run = lab, 1
+        if prev is not None:
+            out.append(prev if run == 1 else f"{prev}({run})")
+        return ";".join(out)
 
     def line(self):
         """merged-file line, Amplicon.py:330-348."""
@@ -63,15 +71,20 @@ def groups_from_records(records, labels, L, D, R, rna=False):
     pre = keys & pm
     new_group = np.ones(len(rec), dtype=bool)
     new_group[1:] = pre[1:] != pre[:-1]
-    groups, amp_labels, cur_key = [], None, None
-    for i in range(len(rec)):
-        if new_key[i]:
-            left, diag, right = codec.key_columns(keys[i], L, D, R, rna)
-            amp = Amplicon(left, diag, right, [])
-            if new_group[i]:
+    # decode every distinct key once, as one byte block of rows left|right|diag
+    k = L + D + R
+    text = codec.keys_to_matrix(keys[new_key], L, D, R, rna).tobytes().decode("ascii")
+    groups, amp, row = [], None, 0
+    for nk, ng, gi, cnt in zip(new_key.tolist(), new_group.tolist(), rec["genome"].tolist(),
+                               rec["count"].tolist()):
+        if nk:
+            s = text[row * k:(row + 1) * k]
+            row += 1
+            amp = Amplicon(s[:L], s[L + R:], s[L:L + R], ())
+            if ng:
                 groups.append([])
             groups[-1].append(amp)
-        amp.labels.extend([labels[int(rec["genome"][i])]] * int(rec["count"][i]))
+        amp.labels.extend([labels[gi]] * cnt)
     for g in groups:
         for a in g:
             a.labels.sort()
@@ -106,12 +119,18 @@ def bracket_line(group, ingroup):
     return "".join(br)
 
 
+_PLAIN_BASES = frozenset("ACGTU")
+
+
 def collapse_to_iupac(seqs):
     """Amplicon.py:42-66."""
     lens = [len(s) for s in seqs]
     width = max(lens)
     if len(set(lens)) != 1:
         return "-" * width
+    first = seqs[0]
+    if _PLAIN_BASES.issuperset(first) and all(s == first for s in seqs):
+        return first              # one plain sequence: every column is its own consensus
     out = []
     for i in range(width):
         col = {s[i] for s in seqs}
