@@ -85,6 +85,13 @@ const char* kr_last_error(kr_ctx*);                            /* ctx may be NUL
  * radix fan-out so that all genomes share one bucket grid). */
 int kr_set_params(kr_ctx*, int L, int D, int R, int softmask_mode, size_t max_bases);
 
+/* Which strands of a window become keys (after kr_set_params, before the first upload).  BOTH is
+ * kstream(complements=True), what krisp_fasta uses (krisp_fasta.py:21-43); FORWARD is neither
+ * option; CANONICAL is kstream(canonicals=True): min(window, reverse complement) compared as
+ * plain strings before the column split (kstream.py:679-694).  One key per window for the latter two. */
+enum { KR_STRANDS_BOTH = 0, KR_STRANDS_FORWARD = 1, KR_STRANDS_CANONICAL = 2 };
+int kr_set_strands(kr_ctx*, int mode);
+
 /* H2D copy of one genome's text + all device allocations it needs. */
 int kr_genome_upload(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
 /* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous. */

@@ -19,6 +19,7 @@ WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS = 0, 1, 2, 3
 WIDE_MAX_K = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
+STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
           "fallback", "intersect", "compact", "collect", "merge", "locate"]
 # stage -> the kernel(s) it times (names as rocprofv3 prints them)
@@ -37,6 +38,7 @@ SYMBOLS = [
     ("kr_destroy", None, [_P]),
     ("kr_last_error", _c.c_char_p, [_P]),
     ("kr_set_params", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_size_t]),
+    ("kr_set_strands", _c.c_int, [_P, _c.c_int]),
     ("kr_genome_upload", _c.c_int, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_genome_sort", _c.c_int, [_P, _c.c_int]),
     ("kr_genome_add", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
@@ -151,6 +153,10 @@ class Engine:
         self._check(self.lib.kr_set_params(self.ctx, L, D, R, SOFT_OMIT if omit_soft else SOFT_MAP,
                                            max_bases), "kr_set_params")
         self.params = (L, D, R)
+
+    def set_strands(self, mode):
+        """STRANDS_BOTH (complements), STRANDS_FORWARD, STRANDS_CANONICAL (kstream canonicals)"""
+        self._check(self.lib.kr_set_strands(self.ctx, mode), "kr_set_strands")
 
     # ---- genomes
     def upload(self, gid, bases):

@@ -49,6 +49,22 @@ def keys_to_lines_bytes(keys, L, D, R, rna=False):
     return out.tobytes()
 
 
+def keys_to_fields_bytes(keys, fields, rna=False):
+    """keys whose bases are the window in line order (engine geometry (k, 0, 0)) -> bytes of the
+    sorted output: the window cut into `fields` (widths, empty ones included) joined by ','."""
+    k = sum(fields)
+    m = keys_to_matrix(keys, k, 0, 0, rna)
+    out = np.empty((len(m), k + len(fields)), dtype=np.uint8)
+    src = dst = 0
+    for w in fields:
+        out[:, dst:dst + w] = m[:, src:src + w]
+        out[:, dst + w] = ord(",")
+        src += w
+        dst += w + 1
+    out[:, k + len(fields) - 1] = ord("\n")
+    return out.tobytes()
+
+
 def key_columns(key, L, D, R, rna=False):
     """one key -> (left, diag, right) str."""
     lut = "ACGU" if rna else "ACGT"

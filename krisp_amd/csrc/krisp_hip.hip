@@ -31,6 +31,8 @@ struct Geom {
     u64 topmask;    // top 2k bits
     u64 mL, mR, mD; // destination masks of left / right / diag in [left|right|diag]
     int omit;       // soft-mask rule
+    int strands;    // 0 both strands of every window (krisp_fasta), 1 forward only, 2 canonical = the
+                    // smaller of window / reverse complement (kstream.py:679-694); 1 and 2: kernels <2>
     // --- key-space slice: genomes too large for one sort unit are sorted in 4^sb slices, one
     // per value of the first sb bases of `left`; inside a slice keys are stored RELATIVE
     // (absolute key << sbits): the slice is the same problem with geometry (L - sb, D, R)
@@ -138,6 +140,24 @@ __device__ __forceinline__ bool window_keys(u64 c0, u64 c1, u32 b0, u32 b1, int 
     u64 wr = y & g.topmask;
     kf = layout_key(wf, g);
     kr = layout_key(wr, g);
+    return true;
+}
+
+// one key per window: the forward strand, or the canonical one (compared as plain strings,
+// before the column layout, as kstream compares them before _split)
+__device__ __forceinline__ bool window_key_single(u64 c0, u64 c1, u32 b0, u32 b1, int j, const Geom& g, u64& key) {
+    u64 x = j ? ((c0 << (2 * j)) | (c1 >> (64 - 2 * j))) : c0;
+    u32 bm = j ? ((b0 << j) | (b1 >> (32 - j))) : b0;
+    if ((bm >> (32 - g.k)) != 0) return false;
+    u64 w = x & g.topmask;
+    if (g.strands == 2) {
+        u64 y = ~(x >> (64 - 2 * g.k));
+        y = __brevll(y);
+        y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+        const u64 wr = y & g.topmask;
+        w = wr < w ? wr : w;
+    }
+    key = layout_key(w, g);
     return true;
 }
 
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
     for (u64 w = w0 + threadIdx.x; w < w1; w += P1_T) {
         u32 b0 = bad[w], b1 = bad[w + 1];
         if (b0 == 0xFFFFFFFFu) continue;
-        if (WIDE) {
+        if (WIDE == 1) {
             for (int j = 0; j < 32; j++) {
                 u64 kf, kr;
                 const u32 m = wide_keys(codes, bad, w * 32 + j, g, kf, kr);
@@ -326,6 +346,15 @@ __global__ __launch_bounds__(P1_T) void k_hist8(const u64* __restrict__ codes, c
             continue;
         }
         u64 c0 = codes[w], c1 = codes[w + 1];
+        if (WIDE == 2) {
+#pragma unroll 4
+            for (int j = 0; j < 32; j++) {
+                u64 k1;
+                if (window_key_single(c0, c1, b0, b1, j, g, k1) && slice_key(k1, g))
+                    atomicAdd(&lhist[(u32)(k1 >> 56)], 1u);
+            }
+            continue;
+        }
         if (cheap) {
 #pragma unroll 8
             for (int j = 0; j < 32; j++) {
@@ -502,13 +531,23 @@ __global__ __launch_bounds__(P1_T, P1_OCC) void k_scatter1(const u64* __restrict
         if (w < w1) {
             u32 b0 = bad[w], b1 = bad[w + 1];
             if (b0 != 0xFFFFFFFFu) {
-                if (WIDE) {
+                if (WIDE == 1) {
 #pragma unroll
                     for (int jj = 0; jj < P1_PPT; jj++) {
                         u64 kf, kr;
                         const u32 m = wide_keys(codes, bad, w * 32 + j0 + jj, g, kf, kr);
                         if ((m & 1) && slice_key(kf, g)) { key[2 * jj] = kf; vm |= 1u << (2 * jj); }
                         if ((m & 2) && slice_key(kr, g)) { key[2 * jj + 1] = kr; vm |= 2u << (2 * jj); }
+                    }
+                } else if (WIDE == 2) {
+                    u64 c0 = codes[w], c1 = codes[w + 1];
+#pragma unroll
+                    for (int jj = 0; jj < P1_PPT; jj++) {
+                        u64 k1;
+                        if (window_key_single(c0, c1, b0, b1, j0 + jj, g, k1) && slice_key(k1, g)) {
+                            key[2 * jj] = k1;
+                            vm |= 1u << (2 * jj);
+                        }
                     }
                 } else {
                     u64 c0 = codes[w], c1 = codes[w + 1];
@@ -2006,6 +2045,15 @@ int kr_set_params(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_
     return KR_OK;
 }
 
+int kr_set_strands(kr_ctx* c, int mode) {
+    if (!c || !c->have_params) return fail(c, KR_ERR_STATE, "kr_set_params first");
+    if (mode < KR_STRANDS_BOTH || mode > KR_STRANDS_CANONICAL) return fail(c, KR_ERR_PARAM, "unknown strand mode %d", mode);
+    if (c->wide.on) return fail(c, KR_ERR_PARAM, "the wide path emits both strands only");
+    if (!c->genomes.empty()) return fail(c, KR_ERR_STATE, "kr_set_strands after genomes were uploaded");
+    c->g.strands = mode;
+    return KR_OK;
+}
+
 int kr_set_params_wide(kr_ctx* c, int L, int D, int R, int softmask_mode, size_t max_bases) {
     if (!c) return KR_ERR_PARAM;
     const int k = L + D + R;
@@ -2073,9 +2121,22 @@ static void launch_pack(kr_ctx* c, Genome& G, Lane& ln, hipStream_t st) {
                        (u64*)ln.codes.p, (u32*)ln.bad.p, nwp, c->g.omit);
 }
 
+static void launch_scatter1(const Geom& g, hipStream_t st, const u64* codes, const u32* bad, u64 nwords,
+                            const u32* base1, const u64* base64, const u32* rowoff, u64* dst) {
+    if (g.wmode)
+        hipLaunchKernelGGL(k_scatter1<1>, dim3(NWG), dim3(P1_T), 0, st, codes, bad, nwords, base1, base64, rowoff, dst, g);
+    else if (g.strands)
+        hipLaunchKernelGGL(k_scatter1<2>, dim3(NWG), dim3(P1_T), 0, st, codes, bad, nwords, base1, base64, rowoff, dst, g);
+    else
+        hipLaunchKernelGGL(k_scatter1<0>, dim3(NWG), dim3(P1_T), 0, st, codes, bad, nwords, base1, base64, rowoff, dst, g);
+}
+
 static void launch_hist8(kr_ctx* c, Genome& G, Lane& ln, hipStream_t st, const Geom& g) {
     if (g.wmode)
         hipLaunchKernelGGL(k_hist8<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
+                           G.nwords, (u32*)ln.partial8.p, g);
+    else if (g.strands)
+        hipLaunchKernelGGL(k_hist8<2>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
                            G.nwords, (u32*)ln.partial8.p, g);
     else
         hipLaunchKernelGGL(k_hist8<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)ln.codes.p, (const u32*)ln.bad.p,
@@ -2205,14 +2266,8 @@ static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
         g0.wcmode = (g0.wmode == 2 && g0.wcache && c->nlanes == 1) ? 2 : 0;
         (void)cached_keys;
         StageScope sc(c, KR_ST_SCATTER1, st);
-        if (g0.wmode)
-            hipLaunchKernelGGL(k_scatter1<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                               (const u32*)nullptr, (const u64*)ln.base64.p, (const u32*)ln.partial8.p,
-                               (u64*)ln.pass0.p, g0);
-        else
-            hipLaunchKernelGGL(k_scatter1<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad, G.nwords,
-                               (const u32*)nullptr, (const u64*)ln.base64.p, (const u32*)ln.partial8.p,
-                               (u64*)ln.pass0.p, g0);
+        launch_scatter1(g0, st, (const u64*)codes, (const u32*)bad, G.nwords, (const u32*)nullptr,
+                        (const u64*)ln.base64.p, (const u32*)ln.partial8.p, (u64*)ln.pass0.p);
     }
     u64 region = 0;       // start of the current slice inside the pass-0 array
     for (int s = 0; s < c->nslices; s++) {
@@ -2244,14 +2299,9 @@ static int genome_sort(kr_ctx* c, int id, bool reuse_count) {
             if (sliced)
                 hipLaunchKernelGGL(k_scatter1k, dim3(NWG), dim3(P1_T), 0, st, src, (u64)S.nmax, g.sbits,
                                    (const u32*)ln.base1.p, (const u32*)ln.partial8.p, pass1_dst);
-            else if (g.wmode)
-                hipLaunchKernelGGL(k_scatter1<1>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad,
-                                   G.nwords, (const u32*)ln.base1.p, (const u64*)nullptr, (const u32*)ln.partial8.p,
-                                   pass1_dst, g);
             else
-                hipLaunchKernelGGL(k_scatter1<0>, dim3(NWG), dim3(P1_T), 0, st, (const u64*)codes, (const u32*)bad,
-                                   G.nwords, (const u32*)ln.base1.p, (const u64*)nullptr, (const u32*)ln.partial8.p,
-                                   pass1_dst, g);
+                launch_scatter1(g, st, (const u64*)codes, (const u32*)bad, G.nwords, (const u32*)ln.base1.p,
+                                (const u64*)nullptr, (const u32*)ln.partial8.p, pass1_dst);
         }
         if (g.b > 8) {
             const u32 ntmax = (u32)(S.nmax / P2_TILE) + 257;

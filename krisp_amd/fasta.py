@@ -98,6 +98,17 @@ def ingest(source, k, omit_soft):
     return bases, rna, special
 
 
+def load_any(source):
+    """file name or iterable of sequence strings -> (upload buffer, is_rna, number of characters
+    outside ACGTNacgtn), nothing resolved"""
+    if isinstance(source, (str, os.PathLike)):
+        return load_bases(os.fspath(source))
+    records = read_records(source)
+    rna = bool(detect_rna(records))
+    bases = to_bases(records, rna)
+    return bases, rna, int(np.count_nonzero(~_PLAIN[bases]))
+
+
 def detect_rna(records):
     for s in records:
         if b"T" in s or b"t" in s:

@@ -2,12 +2,17 @@
 
 Same constructor, iteration, call and write() contract as the reference class
 (kstream/kstream.py:122-428) and the same `kstream` command line
-(kstream.py:835-952).  The option combination krisp_fasta uses
+(kstream.py:835-952).  Sorted single-k streams run on the GPU through
+libkrisp_hip.so (`kstream.device_plan`): the option combination krisp_fasta uses
 (krisp_fasta.py:21-43: kmers=k, complements, disallow="Nn", omitsoft|mapsoft,
-split=[L,-R], sort with sortcols=[0,2]) runs on the GPU through
-libkrisp_hip.so -- and ONLY there: no CPU path exists for it, a missing library
-raises.  Every other combination is outside the accelerated hot path
- and is served by the plain host generator chain below.
+split=[L,-R], sort with sortcols=[0,2]) and its neighbours -- forward strand only or
+canonicals instead of complements, no split or a one-sided split, sort columns that
+leave the fields in line order.  No CPU sort or k-mer generation stands in for that
+route when the library is missing: it raises.  Option sets outside it (allow,
+expand-iupac, several k, unsorted streaming, kept lower case, other column orders) are
+outside the accelerated hot path and are served by the plain host
+generator chain below, as are inputs holding characters the 2-bit alphabet cannot carry
+under the forward / canonical modes.
 """
 import argparse
 import itertools
@@ -29,6 +34,31 @@ _WRITE_CHUNK = 1 << 22      # keys decoded to text per chunk
 
 def _revcomp(s):
     return "".join([COMP_MAP[c] for c in reversed(s)])   # KeyError as kstream.py:658
+
+
+def _rewindable(sequences):
+    """a one-shot iterator may have to be read twice (device attempt, then the host chain): keep
+    its items; the reference's first-line quirk for one-shot inputs (kstream.py:450) is preserved
+    by handing on an iterator again"""
+    if isinstance(sequences, (str, bytes)) or hasattr(sequences, "__fspath__") or not hasattr(sequences, "__next__"):
+        return sequences
+    return _Replay(list(sequences))
+
+
+class _Replay:
+    """list-backed stand-in for a one-shot iterator: every iter() starts over, and it still
+    looks one-shot (has __next__) to the reader's first-line rule"""
+
+    def __init__(self, items):
+        self.items = items
+        self._it = iter(items)
+
+    def __iter__(self):
+        self._it = iter(self.items)
+        return self
+
+    def __next__(self):
+        return next(self._it)
 
 
 class kstream:
@@ -61,38 +91,108 @@ class kstream:
 
     # ------------------------------------------------------------------ device path
     def device_geometry(self):
-        """(L, D, R) when this option set is the accelerated krisp_fasta combination."""
+        """(L, D, R) when this option set is THE krisp_fasta combination (krisp_fasta.py:21-43)."""
+        plan = self.device_plan()
+        if plan is None or plan["strands"] != 0 or plan["layout"] != "lrd" or len(plan["fields"]) != 3:
+            return None
+        return plan["geometry"]
+
+    def device_plan(self):
+        """How the GPU serves this option set, or None (-> the host generator chain).
+
+        Accelerated: one k <= 32; both strands (complements), forward only, or canonicals; one of
+        omitsoft / mapsoft; disallow == 'Nn'; sort=True; split None, [a], [a, -b] (a, b >= 0);
+        sort columns that order the line's fields as (all fields in line order) or
+        (first, last, middle) -- GNU sort falls back to the whole line, so any column list is a
+        permutation of the fields followed by line order.  The window is packed as ONE key whose
+        unsigned order is that field order:
+          layout 'ldr'  the window as it is            -> engine geometry (k, 0, 0)
+          layout 'lrd'  first | last | middle field    -> engine geometry (first, middle, last)
+        Everything else the reference supports (allow, expand-iupac, several k, unsorted streaming,
+        other column orders, keeping lower case) stays on the host chain."""
         if self.kmers is None or len(self.kmers) != 1:
             return None
         k = self.kmers[0]
-        if not (1 <= k <= 32) or not self.complements or self.canonicals:
+        if not (1 <= k <= 32):
             return None
         if self.allow is not None or self.expandiupac or self.disallow != {"N", "n"}:
             return None
-        if self.omitsoft == self.mapsoft:
+        if self.omitsoft == self.mapsoft or self.sort is not True:
             return None
-        if self.sort is not True or self.sortcols is None or list(self.sortcols) != [0, 2]:
+        strands = 0 if self.complements else (2 if self.canonicals else 1)
+        # fields of the output line (kstream.py:805-832)
+        if self.split is None:
+            fields = [k]
+        else:
+            if len(self.split) not in (1, 2):
+                return None
+            a = self.split[0]
+            if a < 0 or a > k:
+                return None
+            if len(self.split) == 1:
+                fields = [a, k - a]
+            else:
+                b = self.split[1]
+                if b > 0 or a - b > k:
+                    return None
+                fields = [a, 0, k - a] if b == 0 else [a, k - a + b, -b]     # kstream.py:824-830
+        # effective order of the fields: listed columns, then line order
+        cols = [] if self.sortcols is None else list(self.sortcols)
+        if any((not isinstance(c, int)) or c < 0 or c >= len(fields) for c in cols):
             return None
-        if self.split is None or len(self.split) != 2:
+        order = []
+        for c in cols + list(range(len(fields))):
+            if c not in order:
+                order.append(c)
+        order = [c for c in order if fields[c] > 0]            # empty fields do not order anything
+        natural = [c for c in range(len(fields)) if fields[c] > 0]
+        if len(fields) == 3 and order == [c for c in (0, 2, 1) if fields[c] > 0]:
+            layout, geometry = "lrd", (fields[0], fields[1], fields[2])
+        elif order == natural:
+            layout, geometry = "ldr", (k, 0, 0)
+        else:
             return None
-        a, b = self.split
-        if a < 0 or b > 0 or a - b > k:
+        if geometry[1] > 16:
             return None
-        geo = (a, 0, k - a) if b == 0 else (a, k - a + b, -b)     # kstream.py:824-830
-        if geo[1] > 16:
-            return None
-        return geo
+        return dict(k=k, fields=fields, layout=layout, geometry=geometry, strands=strands)
 
-    def _device_keys(self, sequences, geo):
+    def _device_keys(self, sequences, plan):
+        """-> (sorted keys, is_rna, IUPAC k-mers as field tuples) or None when the input holds
+        characters the device alphabet cannot carry in a way only the host chain reproduces."""
         from . import _native
-        L, D, R = geo
-        bases, rna, windows = fasta.ingest(sequences, L + D + R, self.omitsoft)
-        special = [codec.split_window(w, L, D, R) for w in windows]
+        L, D, R = plan["geometry"]
+        krisp_combo = plan["strands"] == 0 and plan["layout"] == "lrd" and len(plan["fields"]) == 3
+        if krisp_combo:
+            bases, rna, windows = fasta.ingest(sequences, plan["k"], self.omitsoft)
+            special = [codec.split_window(w, L, D, R) for w in windows]
+        else:
+            # forward / canonical strands, other layouts: anything outside ACGTNacgtn (IUPAC
+            # letters are kept by the reference, other characters pass or raise depending on
+            # the strand option) goes to the host chain as a whole
+            bases, rna, nspecial = fasta.load_any(sequences)
+            if nspecial:
+                return None
+            special = []
         with _native.Engine(device=self.device) as eng:
             eng.set_params(L, D, R, omit_soft=self.omitsoft, max_bases=len(bases))
+            if plan["strands"]:
+                eng.set_strands(plan["strands"])
             eng.add(0, bases)
             keys = eng.keys(0).copy()
         return keys, rna, special
+
+    def _device_blocks(self, sequences, plan):
+        """-> (iterator of byte blocks of the sorted output, line count) or None"""
+        got = self._device_keys(sequences, plan)
+        if got is None:
+            return None
+        keys, rna, special = got
+        if plan["layout"] == "lrd" and len(plan["fields"]) == 3:
+            blocks = codec.merged_line_blocks(keys, special, *plan["geometry"], rna=rna, chunk=_WRITE_CHUNK)
+        else:
+            blocks = (codec.keys_to_fields_bytes(keys[i:i + _WRITE_CHUNK], plan["fields"], rna)
+                      for i in range(0, len(keys), _WRITE_CHUNK))
+        return blocks, int(len(keys)) + len(special)
 
     # ------------------------------------------------------------------ host chain
     def _host_stream(self, sequences):
@@ -169,12 +269,19 @@ class kstream:
 
     # ------------------------------------------------------------------ public surface
     def __call__(self, sequences):
-        geo = self.device_geometry()
-        if geo is not None:
-            keys, rna, special = self._device_keys(sequences, geo)
-            for blob in codec.merged_line_blocks(keys, special, *geo, rna=rna, chunk=_WRITE_CHUNK):
-                yield from blob.decode("ascii").split("\n")[:-1]
-            return
+        plan = self.device_plan()
+        if plan is not None:
+            sequences = _rewindable(sequences)
+            got = self._device_blocks(sequences, plan)
+            if got is not None:
+                for blob in got[0]:
+                    yield from blob.decode("ascii").split("\n")[:-1]
+                return
+        yield from self.host_lines(sequences)
+
+    def host_lines(self, sequences):
+        """the plain host generator chain, whatever the option set (the fallback of the device
+        route and the CPU tests' handle on it)"""
         seqs, rna = self._host_stream(sequences)
         if self.sort:
             seqs = self._host_sorted(list(seqs))
@@ -189,13 +296,15 @@ class kstream:
         """kstream.py:250-325: write (sorted) k-mers, return their number."""
         if sequences is None:
             sequences = self.sequences
-        geo = self.device_geometry()
-        if geo is not None:
-            keys, rna, special = self._device_keys(sequences, geo)
-            with open(filename, "wb") as f:
-                for blob in codec.merged_line_blocks(keys, special, *geo, rna=rna, chunk=_WRITE_CHUNK):
-                    f.write(blob)
-            return int(len(keys)) + len(special)
+        plan = self.device_plan()
+        if plan is not None:
+            sequences = _rewindable(sequences)
+            got = self._device_blocks(sequences, plan)
+            if got is not None:
+                with open(filename, "wb") as f:
+                    for blob in got[0]:
+                        f.write(blob)
+                return got[1]
         seqs, rna = self._host_stream(sequences)
         if rna:
             seqs = (s.replace("T", "U").replace("t", "u") for s in seqs)

@@ -169,6 +169,50 @@ def kstream_cases():
     return cases
 
 
+def kstream_cases_more():
+    """kstream option combinations beyond the krisp_fasta one that the device path also serves
+    (strand mode x soft-mask rule x split x sort columns); written to kstream_cases_more.json."""
+    cases = []
+
+    def add(name, kwargs, seqs=None, file_text=None, fname="in.fa", use_write=False):
+        res = run_kstream(kwargs, seqs, file_text, fname, use_write)
+        cases.append({"name": name, "kwargs": kwargs, "seqs": seqs,
+                      "file_text": file_text, "fname": fname,
+                      "use_write": use_write, **res})
+
+    rng = random.Random(11)
+    texts = []
+    for i in range(3):
+        recs = []
+        for r in range(3):
+            n = rng.randint(8, 90)
+            recs.append("".join(rng.choice("ACGT" * 12 + "acgt" * 2 + "Nn") for _ in range(n)))
+        texts.append("".join(f">rec{j} x\n{s}\n" for j, s in enumerate(recs)))
+    strands = {"comp": dict(complements=True), "canon": dict(canonicals=True), "fwd": {}}
+    n = 0
+    for sname, skw in strands.items():
+        for mode in ("mapsoft", "omitsoft"):
+            for split, cols in ((None, None), ([3, -2], None), ([3, -2], [0, 2]), ([4], None), ([2, -3], [0]),
+                                ([0, -3], [0, 2]), ([5, 0], [0, 2])):
+                kw = dict(kmers=7, disallow="Nn", sort=True, **skw)
+                kw[mode] = True
+                if split is not None:
+                    kw["split"] = split
+                if cols is not None:
+                    kw["sortcols"] = cols
+                text = texts[n % len(texts)]
+                add(f"more{n}_{sname}_{mode}_{split}_{cols}", kw, file_text=text, fname=f"m{n % 3}.fa",
+                    use_write=bool(n % 2))
+                n += 1
+    add("more_canon_palindromes", dict(kmers=4, canonicals=True, disallow="Nn", mapsoft=True, sort=True),
+        ["ACGTACGTTTAAACGCGT", "aattAATTGGCC"])
+    add("more_fwd_rna", dict(kmers=5, disallow="Nn", mapsoft=True, sort=True, split=[2, -1]),
+        ["ACGUUGCAUUAG", "GGGuuuACG"], use_write=True)
+    add("more_canon_k32", dict(kmers=32, canonicals=True, disallow="Nn", mapsoft=True, sort=True),
+        ["".join(rng.choice("ACGT") for _ in range(80))])
+    return cases
+
+
 # --------------------------------------------------------------------------
 # 2. krisp_fasta-level cases (stages + final text)
 # --------------------------------------------------------------------------
@@ -371,6 +415,12 @@ def fasta_cases():
 
 
 def main():
+    km = kstream_cases_more()
+    with open(HERE / "kstream_cases_more.json", "w") as f:
+        json.dump(km, f, indent=1)
+    print(f"kstream cases (more): {len(km)}")
+    if "--more-only" in sys.argv:
+        return
     ks = kstream_cases()
     with open(HERE / "kstream_cases.json", "w") as f:
         json.dump(ks, f, indent=1)

@@ -183,13 +183,19 @@ def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatc
 def _geo(kwargs):
     from krisp_amd.kstream import kstream
     try:
-        return kstream(**kwargs).device_geometry()
+        return kstream(**kwargs).device_plan()
     except ValueError:
         return None
 
 
-@pytest.mark.parametrize("case", [c for c in KS if _geo(c["kwargs"]) is not None], ids=lambda c: c["name"])
+KS_MORE = json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json")))
+
+
+@pytest.mark.parametrize("case", [c for c in KS + KS_MORE if _geo(c["kwargs"]) is not None],
+                         ids=lambda c: c["name"])
 def test_kstream_accelerated_combination(case, tmp_path):
+    """every reference vector whose option set the device serves: the krisp_fasta combination and
+    strand mode x soft-mask rule x split x sort columns (forward only, canonicals, no split ...)"""
     from krisp_amd import fasta
     from krisp_amd.kstream import kstream
     src = case["seqs"]
@@ -380,3 +386,44 @@ def test_wide_path_edge_cases_match_the_text_oracle(name, texts, n_in, tmp_path)
         groups, _ = KF.find_regions(ing, outg, L, R, k)
         got = amplicon.merged_lines(groups)
         assert sorted(got) == sorted(expect), (name, L, D, R)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_kstream_device_route_equals_the_host_chain(seed, tmp_path):
+    """random genomes and option sets: the device route and the host generator chain (pinned to
+    the reference by the golden vectors) write the same file; inputs with IUPAC letters or stray
+    characters take the host chain under the new modes and still agree"""
+    import random
+    from krisp_amd.kstream import kstream
+    rng = random.Random(300 + seed)
+    k = rng.choice([5, 11, 20, 31, 32])
+    alphabet = "ACGT" * 12 + "acgt" * 2 + "Nn" + ("RYKX-" if seed % 5 == 4 else "")
+    recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(k, 4000))) for _ in range(rng.randint(1, 4))]
+    text = "".join(f">r{i}\n{r}\n" for i, r in enumerate(recs))
+    if seed % 4 == 1:
+        text = text.replace("T", "U").replace("t", "u")
+    src = tmp_path / "g.fa"
+    src.write_text(text)
+    for strands in (dict(complements=True), dict(canonicals=True), {}):
+        a = rng.randint(0, k)
+        b = rng.randint(0, k - a)
+        split, cols = rng.choice([(None, None), ([a], None), ([a, -b], None), ([a, -b], [0, 2]), ([a, -b], [0])])
+        kw = dict(kmers=k, disallow="Nn", sort=True, **strands)
+        kw[rng.choice(["mapsoft", "omitsoft"])] = True
+        if split is not None:
+            kw["split"] = split
+        if cols is not None:
+            kw["sortcols"] = cols
+        ks = kstream(**kw)
+        if ks.device_plan() is None:
+            continue
+        try:
+            want = list(ks.host_lines(str(src)))
+        except KeyError as e:
+            with pytest.raises(KeyError):
+                ks.write(str(tmp_path / "out.txt"), str(src))
+            continue
+        out = tmp_path / "out.txt"
+        assert ks.write(str(out), str(src)) == len(want), kw
+        assert out.read_text().split("\n")[:-1] == want, kw
+        assert list(ks(str(src))) == want

@@ -42,9 +42,23 @@ def test_read_records_matches_reference_reader(case, tmp_path):
 
 def _safe_geometry(kwargs):
     try:
-        return kstream(**kwargs).device_geometry()
+        return kstream(**kwargs).device_plan()
     except ValueError:
         return None
+
+
+KS_MORE = json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json")))
+
+
+@pytest.mark.parametrize("case", KS_MORE, ids=lambda c: c["name"])
+def test_kstream_host_chain_on_the_device_served_combinations(case, tmp_path):
+    """strand mode x soft-mask rule x split x sort columns: the host chain (the device route's
+    fallback) against vectors captured from the reference; the same cases run on the GPU in
+    test_gpu_cli.py"""
+    src = _src(case, tmp_path)
+    ks = kstream(**case["kwargs"])
+    assert ks.device_plan() is not None
+    assert list(ks.host_lines(src)) == case["out"]
 
 
 @pytest.mark.parametrize("case", [c for c in KS if "raises" in c or _safe_geometry(c["kwargs"]) is None],
@@ -57,7 +71,7 @@ def test_kstream_host_chain_matches_reference(case, tmp_path):
                 kstream(**case["kwargs"])
             return
         ks = kstream(**case["kwargs"])
-        if ks.device_geometry() is not None:
+        if ks.device_plan() is not None:
             pytest.skip("accelerated combination: covered by the gpu tests")
         with pytest.raises(Exception) as ei:
             list(ks(src))
@@ -84,6 +98,19 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
                    dict(mapsoft=False), dict(sort=False), dict(sortcols=None), dict(sortcols=[0]),
                    dict(allow="ACGT"), dict(expandiupac=True), dict(split=None), dict(kmers=[28, 29])):
         assert kstream(**dict(base, **change)).device_geometry() is None, change
+    # the wider device route: strand modes, other splits and column orders
+    plan = kstream(**base).device_plan()
+    assert plan["layout"] == "lrd" and plan["strands"] == 0 and plan["geometry"] == (25, 1, 2)
+    assert kstream(**dict(base, complements=False)).device_plan()["strands"] == 1
+    assert kstream(**dict(base, complements=False, canonicals=True)).device_plan()["strands"] == 2
+    for change in (dict(sortcols=None), dict(sortcols=[0]), dict(sortcols=[0, 1, 2]), dict(split=None, sortcols=None),
+                   dict(split=[25], sortcols=None)):
+        p = kstream(**dict(base, **change)).device_plan()
+        assert p["layout"] == "ldr" and p["geometry"] == (28, 0, 0), change
+    for change in (dict(kmers=33, split=[30, -2]), dict(disallow="N"), dict(mapsoft=False), dict(sort=False),
+                   dict(allow="ACGT"), dict(expandiupac=True), dict(kmers=[28, 29]), dict(sortcols=[1]),
+                   dict(sortcols=[2]), dict(sortcols=[1, 0]), dict(split=[5, -3], sortcols=[0, 2])):
+        assert kstream(**dict(base, **change)).device_plan() is None, change
 
 
 def test_codec_roundtrip_and_oracle_agreement():
