@@ -971,8 +971,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
                 // keys are walked in PLACED order: lanes of a wave rank neighbours, so their LDS reads
                 // are adjacent and their global stores fall into one or two 512-byte runs.  (Measured,
                 // tools/ls_ablate.py: load + store alone 0.34 ms per 10^8 keys, binning adds nothing,
-                // this step 0.17 ms; staging the ranked keys through LDS for fully coalesced stores,
-                // fewer barriers and unconditional neighbour reads were all A/B-tested: no gain.)
+                // this step 0.17 ms -- all of it the divergent loop below (storing in placed order
+                // instead costs the same); staging the ranked keys through LDS, fewer barriers,
+                // unconditional neighbour reads, 8192 sub-bins, 1024 threads / higher occupancy and
+                // non-temporal stores were all A/B-tested: no gain.)
 #pragma unroll 2
                 for (int i = 0; i < (int)LS_PER; i++) {
                     u32 p = tid + i * LS_THREADS;
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
                             u64 kq = S[q];
                             rank += (kq < kk) || (kq == kk && q < p);
                         }
-                        keys[s + rank] = kk;
+                        keys[s + ((dbg & 256) ? p : rank)] = kk;    // (256: kr_debug_localsort, ranked but stored in place)
                     }
                 }
             } else {
