@@ -973,8 +973,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_localsort(u64* __restrict__ keys
                 // tools/ls_ablate.py: load + store alone 0.34 ms per 10^8 keys, binning adds nothing,
                 // this step 0.17 ms -- all of it the divergent loop below (storing in placed order
                 // instead costs the same); staging the ranked keys through LDS, fewer barriers,
-                // unconditional neighbour reads, 8192 sub-bins, 1024 threads / higher occupancy and
-                // non-temporal stores were all A/B-tested: no gain.)
+                // unconditional neighbour reads, ranking through wave shuffles (halo lanes), 8192
+                // sub-bins, 1024 threads / higher occupancy and non-temporal stores were all
+                // A/B-tested: no gain.)
 #pragma unroll 2
                 for (int i = 0; i < (int)LS_PER; i++) {
                     u32 p = tid + i * LS_THREADS;
