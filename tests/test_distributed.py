@@ -55,7 +55,8 @@ WORKER = textwrap.dedent('''
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    fam = synth.family(5, 3, 3, 6000, records=2, mu=0.004, snp_every=500)
+    ng = max(6, world)
+    fam = synth.family(5, ng // 2, ng - ng // 2, 6000, records=2, mu=0.004, snp_every=500)
     mine = D.shard(list(range(len(fam))), rank, world)
     keys = [K.sorted_keys(fam[g][2].tobytes(), L, Dg, R) for g in mine]
     eng = OracleEngine(keys, [fam[g][1] for g in mine])
@@ -91,7 +92,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_tree_reduce_over_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
