@@ -1,6 +1,8 @@
 """Property tests of the GPU path against the packed-key oracle: random geometries,
 alphabets (soft mask, N runs), record layouts, genome counts and in/out assignments
 (hypothesis, derandomised so the GPU box and this container draw the same examples)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -45,7 +47,7 @@ def _genomes(n, alphabet, base_len, mu, seed):
     return out
 
 
-@settings(max_examples=60, deadline=None, derandomize=True,
+@settings(max_examples=int(os.environ.get("KR_HYP_EXAMPLES", "60")), deadline=None, derandomize=True,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 @given(workload())
 def test_gpu_matches_oracle_on_random_workloads(w):
