@@ -73,13 +73,13 @@ __device__ __forceinline__ bool slice_key(u64& key, const Geom& g) {
 #define NWG 2048           // persistent workgroups of the histogram / pass-1 kernels (A/B: 2048 beats 1024 by ~7 % on k_scatter1)
 #endif
 #ifndef P1_T
-#define P1_T 256           // threads of those workgroups
+#define P1_T 512           // threads of those workgroups
 #endif
 #ifndef P1_WORDS
-#define P1_WORDS 64        // code words per pass-1 tile (2048 positions, <= 4096 keys)
-#endif
+#define P1_WORDS 128       // code words per pass-1 tile (4096 positions, <= 8192 keys): a tile's 256 digit runs are
+#endif                     // 256 bytes each; with 64 words / 256 threads (128-byte runs) k_scatter1 took 30 % longer
 #ifndef P1_OCC
-#define P1_OCC 3           // waves per SIMD k_scatter1 is compiled for (= resident workgroups per CU at 256 threads)
+#define P1_OCC 4           // waves per SIMD k_scatter1 is compiled for: 2 workgroups of 512 threads per CU (128 VGPRs)
 #endif
 #define P1_TPW (P1_T / P1_WORDS)        // threads per code word
 #define P1_PPT (32 / P1_TPW)            // window positions per thread
