@@ -18,7 +18,8 @@ def hipcc():
 
 
 def build(force=False, verbose=False):
-    deps = [SRC, os.path.join(INC, "krisp_hip.h")]
+    csrc = os.path.dirname(SRC)          # krisp_hip.hip #includes its parts (k_*.inc kernels, h_*.inc host)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INC, "krisp_hip.h")]
     if (not force and os.path.exists(LIB)
             and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
         return LIB
