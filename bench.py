@@ -104,6 +104,8 @@ def main():
                     help="bases per genome of the CPU baseline sample (0 = calibrate to ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse the N > 1 flow with several ranks sharing the visible GPU(s)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) even at world size 1 (plumbing self-test)")
     args = ap.parse_args()
@@ -123,9 +125,14 @@ def main():
     if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        device = torch.device("cuda", local_rank)
+        if args.dist_backend == "gloo":            # rehearsal: ranks share the GPU(s), lists travel over gloo
+            local_rank %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            device = torch.device("cuda", local_rank)
     from krisp_amd.distributed import tree_reduce_candidates
 
     L, D, R = args.ldr
@@ -185,10 +192,10 @@ def main():
     copy_gbps = eng.copy_gbps(1 << 30, 10) if rank == 0 else None      # measured streaming-copy peak of this box
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        k = torch.tensor([kmers_local], dtype=torch.int64, device=device)
+        k = torch.tensor([kmers_local], dtype=torch.int64, device=device if device is not None else "cpu")
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
         kmers_total = int(k.item())
     else:
