@@ -210,6 +210,58 @@ def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter):
     return touched, groups
 
 
+def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, geo, ingroup, do_filter):
+    """Wide-path twin of _special_groups.  A touched (left,right) pair with an IUPAC letter in a
+    flank can only hold IUPAC k-mers (the host has them all); a pair with plain flanks also
+    holds ACGT windows, which the device locates: one kr_wide_run per genome against a probe
+    genome made of the touched pairs (left + A..A + right) returns every window of that genome
+    whose flanks are one of them."""
+    from . import _native
+    L, D, R = geo
+    n = len(texts)
+    members = {}            # (left,right) -> {(left,diag,right) -> {genome index -> count}}
+    if probes:
+        wanted = set(probes)
+        pid = n             # genome id of the probe
+        eng.upload(pid, probe_text)
+        for gi in range(n):
+            nh = eng.wide_run([pid, gi], [True, True], apply_filter=False)
+            if not nh:
+                continue
+            hits = eng.wide_fetch(_native.WIDE_HITS)
+            hits = hits[hits["genome"] == 1].copy()
+            hits["genome"] = 0
+            for g in _groups_from_hits(hits, [texts[gi]], ["x"], L, D, R):
+                for a in g:
+                    if (a.left, a.right) in wanted:
+                        m = members.setdefault((a.left, a.right), {}).setdefault((a.left, a.diag, a.right), {})
+                        m[gi] = m.get(gi, 0) + len(a.labels)
+    for gi, sp in enumerate(specials):
+        for (l, d, r) in sp:
+            m = members.setdefault((l, r), {}).setdefault((l, d, r), {})
+            m[gi] = m.get(gi, 0) + 1
+    groups = []
+    for P in sorted(members):
+        if P not in touched:
+            continue
+        seqs = members[P]
+        present = set()
+        for m in seqs.values():
+            present.update(m)
+        if len(present) != n:
+            continue
+        group = []
+        for seq in sorted(seqs, key=lambda t: t[1]):
+            labs = []
+            for gi, cnt in seqs[seq].items():
+                labs += [labels[gi]] * cnt
+            group.append(amplicon.Amplicon(seq[0], seq[1], seq[2], labs))
+        if do_filter and not amplicon.ingroup_unique_columns(group, ingroup):
+            continue
+        groups.append(group)
+    return groups
+
+
 def _merge_groups(device_groups, touched, special_groups):
     """device groups minus the ones re-evaluated on the host, plus those; (left,right) byte order"""
     out = [g for g in device_groups if (g[0].left, g[0].right) not in touched] + special_groups
@@ -268,19 +320,28 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
         if quirk_all_fail:
             stats.update(device_s=0.0, kmers=0, candidates=0)
             return [], stats
-        if any(specials):
-            raise fasta.IupacWindowsUnsupported(
-                "IUPAC ambiguity letters inside amplicons longer than 32 bases are not carried yet")
+        # k-mers holding IUPAC letters (kept by the reference): the (left,right) groups they touch
+        # are rebuilt on the host; those with plain flanks need their ACGT members from every
+        # genome, found on the device through a probe "genome" of the touched flank pairs
+        touched = {(l, r) for sp in specials for (l, d, r) in sp}
+        probes = sorted(p for p in touched if _pure(p[0]) and _pure(p[1]))
+        probe_text = np.frombuffer("\n".join(l + "A" * De + r for l, r in probes).encode(), dtype=np.uint8)
         with _native.Engine(device=device) as eng:
-            eng.set_params_wide(Le, De, Re, omit_soft=omit_soft, max_bases=max(len(t) for t in texts))
+            eng.set_params_wide(Le, De, Re, omit_soft=omit_soft,
+                                max_bases=max(max(len(t) for t in texts), len(probe_text)))
             ids = list(range(len(files)))
             for i, t in enumerate(texts):
                 eng.upload(i, t)
             nhits = eng.wide_run(ids, flags, apply_filter=do_filter)
             hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
             ngroups = len(eng.wide_fetch(_native.WIDE_GROUPS))
+            groups = _groups_from_hits(hits, texts, labels, Le, De, Re)
+            if touched:
+                sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text,
+                                               (Le, De, Re), ingroup_labels, do_filter)
+                groups = _merge_groups(groups, touched, sgroups)
         stats.update(device_s=time.time() - t1, kmers=0, candidates=ngroups)
-        return finish(_groups_from_hits(hits, texts, labels, Le, De, Re)), stats
+        return finish(groups), stats
     with _native.Engine(device=device) as eng:
         eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(len(t) for t in texts))
         counts = []

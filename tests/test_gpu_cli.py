@@ -124,10 +124,11 @@ def test_geometries_beyond_the_wide_path_fail_loudly(tmp_path):
     assert KF.find_regions(ing, [], 30, 0, 60)[0] == []   # R = 0 quirk: every group fails the filter
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatch):
     """kr_wide_run (three sorts + locate) against the text-level oracle: k > 32 and D > 16,
-    soft masking, N runs, repeats, several records, with and without key-space slices."""
+    soft masking, N runs, repeats, several records, with and without key-space slices; every
+    fourth seed plants IUPAC ambiguity letters (host side path + probe-genome look-ups)."""
     import random
     from krisp_amd import amplicon
     from krisp_amd import krisp_fasta as KF
@@ -156,6 +157,14 @@ def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatc
         for _ in range(rng.randint(0, 3)):
             a = rng.randrange(len(s))
             s[a:a + rng.randint(1, 4)] = "N" * rng.randint(1, 4)
+        if seed % 4 == 2:                       # IUPAC ambiguity letters: kept by the reference
+            for _ in range(rng.randint(1, 5)):
+                s[rng.randrange(len(s))] = rng.choice("RYKMSWryk")
+            if gi > 0 and rng.random() < 0.7:   # the same letter at the same place in two genomes
+                s[iupac_at] = "R"
+        if seed % 4 == 2 and gi == 0:
+            iupac_at = rng.randrange(len(s))
+            s[iupac_at] = "R"
         if rng.random() < 0.6:
             a = rng.randrange(len(s))
             w = rng.randint(3, 60)
