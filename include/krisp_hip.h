@@ -146,7 +146,8 @@ int64_t kr_wide_run(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ing
 enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted */
        KR_WIDE_DICT_RIGHT = 1,  /* u64: rights present in all genomes, sorted */
        KR_WIDE_GROUPS = 2,      /* u64: composite keys of the groups present in all genomes (before the filter) */
-       KR_WIDE_HITS = 3 };      /* kr_wide_hit */
+       KR_WIDE_HITS = 3,        /* kr_wide_hit */
+       KR_WIDE_COUNTS = 4 };    /* u64 per genome of the last run: its k-mer records (2 x valid windows) */
 int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* returns #elements; out == NULL: size query */
 
 /* Host-side ingest (no GPU involved): the text of a FASTA / sequence-per-line file -> the

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libkrisp_hip.so")
 CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
-WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS = 0, 1, 2, 3
+WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS = 0, 1, 2, 3, 4
 WIDE_MAX_K = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1

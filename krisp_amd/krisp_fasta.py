@@ -335,12 +335,17 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             nhits = eng.wide_run(ids, flags, apply_filter=do_filter)
             hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
             ngroups = len(eng.wide_fetch(_native.WIDE_GROUPS))
+            counts = eng.wide_fetch(_native.WIDE_COUNTS).tolist()
+            if verbose:
+                for f, cnt in zip(files, counts):
+                    print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)
             groups = _groups_from_hits(hits, texts, labels, Le, De, Re)
             if touched:
                 sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text,
                                                (Le, De, Re), ingroup_labels, do_filter)
                 groups = _merge_groups(groups, touched, sgroups)
-        stats.update(device_s=time.time() - t1, kmers=0, candidates=ngroups)
+        stats.update(device_s=time.time() - t1, kmers=int(sum(counts)) + sum(len(sp) for sp in specials),
+                     candidates=ngroups)
         return finish(groups), stats
     with _native.Engine(device=device) as eng:
         eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(len(t) for t in texts))

@@ -108,6 +108,7 @@ def test_wide_amplicons_match_reference_intermediates(case, tmp_path):
     assert sorted(amplicon.merged_lines(groups)) == want
     if "filtered_canon" in case:
         assert stats["candidates"] == len({tuple(ln.split(",")[0:3:2]) for ln in case["merged_canon"]})
+    assert stats["kmers"] == sum(case["sorted"][f]["lines"] for f in case["ingroup"] + case["outgroup"])
     with pytest.raises(KF.UnsupportedGeometry):
         KF.extractSortedKmers(paths[case["ingroup"][0]], case["L"], case["R"], _amplicon(case),
                               str(tmp_path / "x.kmers"), "80%", 1, False, case["omit_soft"])
