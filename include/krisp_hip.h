@@ -185,6 +185,9 @@ int64_t kr_debug_inversions(kr_ctx*, int genome_id);
 /* timing aid: k_localsort re-run `reps` times over a sorted genome; mode 0 = as shipped,
  * 64 = load + store only, 128 = without the ranking step.  Average ms per launch. */
 double  kr_debug_localsort(kr_ctx*, int genome_id, int reps, int mode);
+/* timing aid: the intersect kernel with parts switched off (mode 0 as shipped, 64 keys streamed
+ * but not probed, 128 probed without the LDS update); leaves the candidate set invalid */
+double  kr_debug_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup, int reps, int mode);
 /* measured streaming-copy rate of this device (read + write GB/s): bench.py reports the roofline
  * fraction against it beside the 8 TB/s specification figure */
 double  kr_debug_copy_gbps(kr_ctx*, size_t bytes, int reps);

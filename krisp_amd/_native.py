@@ -68,6 +68,7 @@ SYMBOLS = [
     ("kr_debug_fetch", _c.c_int64, [_P, _c.c_int, _c.c_int, _P, _c.c_size_t]),
     ("kr_debug_inversions", _c.c_int64, [_P, _c.c_int]),
     ("kr_debug_localsort", _c.c_double, [_P, _c.c_int, _c.c_int, _c.c_int]),
+    ("kr_debug_intersect", _c.c_double, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int]),
     ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
 ]

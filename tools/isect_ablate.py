@@ -1,0 +1,19 @@
+"""Where k_intersect's time goes: python tools/isect_ablate.py  (4 x 50 Mbp, 25/1/2)"""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from krisp_amd import _native, synth  # noqa: E402
+
+fam = synth.family(2, 2, 2, 50_000_000, records=16, mu=0.01, snp_every=10000)
+with _native.Engine() as eng:
+    eng.set_params(25, 1, 2, max_bases=max(len(t) for _, _, t in fam))
+    for i, (_, _, t) in enumerate(fam):
+        eng.add(i, t)
+    ids = np.arange(len(fam), dtype=np.int32)
+    flags = np.array([1 if f else 0 for _, f, _ in fam], dtype=np.uint8)
+    n = sum(eng.count(i) for i in range(len(fam)))
+    for mode, what in ((0, "full"), (64, "keys streamed, no probes"), (128, "probes, no LDS update"), (0, "full")):
+        ms = eng.lib.kr_debug_intersect(eng.ctx, _native._ptr(ids), len(ids), _native._ptr(flags), 10, mode)
+        print(f"{what:32s} {ms:.3f} ms  {8 * n / ms / 1e6:.0f} GB/s", flush=True)
