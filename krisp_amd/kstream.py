@@ -18,7 +18,6 @@ import argparse
 import itertools
 import sys
 
-import numpy as np
 
 from . import codec, fasta
 

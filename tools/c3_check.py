@@ -5,7 +5,6 @@ groups ascend, flanks agree, a diagnostic column separates the groups)."""
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, ".")
 from krisp_amd import _native, amplicon, synth  # noqa: E402

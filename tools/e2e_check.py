@@ -1,6 +1,6 @@
 """End-to-end wall time of the krisp_fasta flow on 4 x 50 Mbp synthetic FASTA files
 (plain and gzip): host ingest vs device time.  python tools/e2e_check.py [length]"""
-import gzip, os, sys, tempfile, time
+import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from krisp_amd import synth
 from krisp_amd import krisp_fasta as KF

@@ -2,7 +2,6 @@
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, ".")
 from krisp_amd import _native, synth  # noqa: E402
