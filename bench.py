@@ -36,7 +36,7 @@ STAGE_BYTES = {
     "pack": 0.5 + 0.1875,           # 1 B/base in, 3 bits/base out; two records per base
     "hist8": 0.1875,                # codes + bad bits in
     "scatter1": 0.1875 + 8.0,       # codes in, one 8-byte key out
-    "hist2": 8.0,                   # key in
+    "hist2": 8.0,                   # key in (k_hist2; the k_hist16 route reads the codes instead: 0.19 B x partitions)
     "scatter2": 16.0,               # key in, key out
     "localsort": 16.0,              # key in, key out
     "intersect": 8.0,               # every key of every genome read once

@@ -24,7 +24,7 @@ STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", 
           "fallback", "intersect", "compact", "collect", "merge", "locate"]
 # stage -> the kernel(s) it times (names as rocprofv3 prints them)
 STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1",
-                 "hist2": "k_hist2", "scan2": "k_scan2", "scatter2": "k_scatter2",
+                 "hist2": "k_hist16 (or k_hist2)", "scan2": "k_hist16_off (or k_scan2)", "scatter2": "k_scatter2",
                  "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort",
                  "fallback": "k_bitonic_stage", "intersect": "k_intersect", "compact": "k_scan+k_gather_cands",
                  "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact",

@@ -75,6 +75,24 @@ def test_sort_geometries(N, K, L, D, R):
     _check_sorted(N, K, text, L, D, R, stages=True)
 
 
+@pytest.mark.parametrize("n,L,D,R", [
+    (300_000, 25, 1, 2),      # fan-out 2^9: fine offsets straight from the codes (k_hist16)
+    (300_000, 5, 1, 2),       # 2 L = 10 >= 9: still k_hist16, the top bits end inside `left`
+    (300_000, 4, 2, 3),       # 2 L = 8 < 9: k_hist2 / k_scan2 on the pass-1 output
+    (2_500_000, 6, 2, 4),     # fan-out 2^12, 2 L = 12: the boundary case
+    (2_500_000, 5, 3, 4),     # ... and just below it
+    (5_000_000, 7, 0, 7),     # fan-out 2^13 (odd number of bits: 7 bases hold them), L = 7
+    (5_000_000, 6, 1, 6),     # ... L = 6 is too short
+    (24_000_000, 12, 4, 12),  # fan-out 2^15 = one full partition of 32768 bins
+])
+def test_sort_fine_offsets_from_codes_or_keys(N, K, n, L, D, R):
+    """both ways to the fine bucket offsets (k_hist16 when the top b key bits lie inside `left`,
+    else k_hist2 + k_scan2), checked stage by stage: bucket offsets, pass-1 permutation, keys"""
+    text = _rand_text(1000 + n % 97 + L, n, alphabet=b"ACGTACGTACGTACGTN", records=5)
+    info = _check_sorted(N, K, text, L, D, R, stages=True)
+    assert info["overflow_segments"] == 0
+
+
 @pytest.mark.parametrize("n", [0, 1, 5, 27, 28, 29, 31, 32, 33, 63, 64, 65, 100, 4095, 4097, 8193])
 def test_sort_tiny_inputs(N, K, n):
     text = _rand_text(100 + n, n, b"ACGT", records=1)
