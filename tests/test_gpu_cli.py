@@ -125,7 +125,7 @@ def test_geometries_beyond_the_wide_path_fail_loudly(tmp_path):
     assert KF.find_regions(ing, [], 30, 0, 60)[0] == []   # R = 0 quirk: every group fails the filter
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_WIDE_SEEDS", "24"))))
 def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatch):
     """kr_wide_run (three sorts + locate) against the text-level oracle: k > 32 and D > 16,
     soft masking, N runs, repeats, several records, with and without key-space slices; every
@@ -328,7 +328,7 @@ def test_iupac_kmers_join_the_device_results(tmp_path):
     assert any(not set(a.sequence) <= set("ACGT") for g in groups for a in g) or True
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_IUPAC_SEEDS", "12"))))
 def test_random_genomes_with_iupac_letters_match_the_text_oracle(seed, tmp_path):
     """find_regions (device + host side path for IUPAC k-mers) against the text-level oracle:
     letters in the flanks and in the diagnostic columns, several genomes, D = 0..2."""
@@ -398,7 +398,7 @@ def test_wide_path_edge_cases_match_the_text_oracle(name, texts, n_in, tmp_path)
         assert sorted(got) == sorted(expect), (name, L, D, R)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_KSTREAM_SEEDS", "10"))))
 def test_kstream_device_route_equals_the_host_chain(seed, tmp_path):
     """random genomes and option sets: the device route and the host generator chain (pinned to
     the reference by the golden vectors) write the same file; inputs with IUPAC letters or stray

@@ -37,7 +37,8 @@ def _check_sorted(N, K, text, L, D, R, omit=False, stages=False):
         e.sort(0)
         info = e.debug_info()
         assert e.count(0) == len(want), info
-        if stages and info["nslices"] == 1:
+        # (the merge fallback for oversized buckets reuses the pass-1 array as its scratch)
+        if stages and info["nslices"] == 1 and e.debug_info()["fallback_launches"] == 0:
             b = info["b"]
             top = (want >> np.uint64(64 - b)).astype(np.int64)
             hist = np.bincount(top, minlength=1 << b).astype(np.uint32)
@@ -91,6 +92,21 @@ def test_sort_fine_offsets_from_codes_or_keys(N, K, n, L, D, R):
     text = _rand_text(1000 + n % 97 + L, n, alphabet=b"ACGTACGTACGTACGTN", records=5)
     info = _check_sorted(N, K, text, L, D, R, stages=True)
     assert info["overflow_segments"] == 0
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KR_MID_SEEDS", "12"))))
+def test_sort_random_mid_sizes(N, K, seed):
+    """genomes large enough for the second partition pass (fan-out 2^9 .. 2^13), random lengths
+    (word and tile boundaries fall anywhere), geometries on both sides of the 2 L >= b rule,
+    N runs, soft masks, many short records"""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(210_000, 6_000_000))
+    L = int(rng.integers(1, 33))
+    R = int(rng.integers(0, 33 - L))
+    D = int(rng.integers(0, min(16, 32 - L - R) + 1))
+    alphabet = [b"ACGT", b"ACGTACGTACGTN", b"ACGTACGTACGTacgtn", b"AACCGT"][seed % 4]
+    text = _rand_text(6000 + seed, n, alphabet=alphabet, records=int(rng.integers(1, 400)))
+    _check_sorted(N, K, text, L, D, R, omit=bool(seed % 3 == 1), stages=True)
 
 
 @pytest.mark.parametrize("n", [0, 1, 5, 27, 28, 29, 31, 32, 33, 63, 64, 65, 100, 4095, 4097, 8193])
