@@ -10,7 +10,8 @@ import pytest
 from oracle import krisp_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-KS = json.load(open(os.path.join(GOLDEN, "kstream_cases.json")))
+KS = json.load(open(os.path.join(GOLDEN, "kstream_cases.json"))) + \
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json")))
 FC = json.load(open(os.path.join(GOLDEN, "fasta_cases.json")))
 
 
