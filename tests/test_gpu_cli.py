@@ -437,3 +437,14 @@ def test_kstream_device_route_equals_the_host_chain(seed, tmp_path):
         assert ks.write(str(out), str(src)) == len(want), kw
         assert out.read_text().split("\n")[:-1] == want, kw
         assert list(ks(str(src))) == want
+
+
+def test_integration_md_binding_snippets_run():
+    """the ctypes stubs INTEGRATION.md shows a reference maintainer are executed as written
+    (tools/integration_check.py): README answers through the packed and the wide entry points"""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "integration_check.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "records 10" in out.stdout and "wide hits 10 [0, 1]" in out.stdout
