@@ -448,3 +448,21 @@ def test_integration_md_binding_snippets_run():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "records 10" in out.stdout and "wide hits 10 [0, 1]" in out.stdout
+
+
+def test_kstream_command_line_as_documented(tmp_path):
+    """`python -m krisp_amd.kstream FILE -k 28 --complements --disallow Nn --map-softmask --split 25 -2
+    -s --sort-cols 0 2` prints the reference's sorted 28-mer file"""
+    import subprocess
+    import sys
+    src = os.path.join(GOLDEN, "c1", "ingroup0.fasta.gz")
+    cmd = [sys.executable, "-m", "krisp_amd.kstream", src, "-k", "28", "--complements", "--disallow", "Nn",
+           "--map-softmask", "--split", "25", "-2", "-s", "--sort-cols", "0", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    case = [c for c in FC if c["name"].startswith("c1_") and "ingroup0.fasta.gz" in c["sorted"]][0]
+    assert out.stdout.count(b"\n") == case["sorted"]["ingroup0.fasta.gz"]["lines"]
+    assert hashlib.sha256(out.stdout).hexdigest() == case["sorted"]["ingroup0.fasta.gz"]["sha256"]
+    outp = tmp_path / "o.txt"
+    out2 = subprocess.run(cmd + ["--output", str(outp)], cwd=ROOT, capture_output=True, timeout=300)
+    assert out2.returncode == 0 and outp.read_bytes() == out.stdout
