@@ -466,3 +466,25 @@ def test_kstream_command_line_as_documented(tmp_path):
     outp = tmp_path / "o.txt"
     out2 = subprocess.run(cmd + ["--output", str(outp)], cwd=ROOT, capture_output=True, timeout=300)
     assert out2.returncode == 0 and outp.read_bytes() == out.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_krisp_fasta_command_line_over_several_ranks(world, tmp_path):
+    """python -m torch.distributed.run ... -m krisp_amd.krisp_fasta: genomes sharded over the ranks
+    (here sharing the one GPU, lists over gloo), candidate tree reduction, records gathered to rank 0
+    -- the output is the reference's, byte for byte"""
+    import subprocess
+    import sys
+    case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
+    paths = _paths(case, tmp_path)
+    aln = str(tmp_path / "a.txt")
+    csvp = str(tmp_path / "o.csv")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29600 + world), "-m", "krisp_amd.krisp_fasta"]
+    cmd += [paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
+    cmd += case["main_args"] + ["--out_align", aln, "--out_csv", csvp]
+    env = dict(os.environ, KRISP_DIST_BACKEND="gloo")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert open(csvp).read() == case["csv"]
+    assert open(aln).read() == case["align"]
