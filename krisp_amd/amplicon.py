@@ -7,6 +7,8 @@ outputAlignments.py:26-162).  The diagnostic filter itself runs on the device
 (kr_intersect / kr_cands_merge); nothing here decides which groups survive.
 """
 
+import gc
+
 import numpy as np
 
 from . import codec
@@ -21,6 +23,9 @@ IUPAC_KEY = {tuple(sorted(v)): k for k, v in _AMBIGUOUS.items()}
 IUPAC_KEY[("?",)] = "N"
 
 
+_LABEL_STRINGS = {}
+
+
 class Amplicon:
     """One distinct sequence of a group + the sorted multiset of genome labels
     that carry it (Amplicon.py:154-210)."""
@@ -30,12 +35,23 @@ class Amplicon:
         self.left, self.diag, self.right = left, diag, right
         self.labels = sorted(labels)
 
+    @classmethod
+    def presorted(cls, left, diag, right, labels):
+        """labels already in sorted order (a list this object may keep)"""
+        a = cls.__new__(cls)
+        a.left, a.diag, a.right, a.labels = left, diag, right, labels
+        return a
+
     @property
     def sequence(self):
         return self.left + self.diag + self.right
 
     def label_string(self):
         """Amplicon.py:170-187: name or name(count), ';' joined, names sorted."""
+        key = tuple(self.labels)
+        hit = _LABEL_STRINGS.get(key)
+        if hit is not None:
+            return hit
         out, prev, run = [], None, 0
         for lab in self.labels:                 # (sorted: equal names are adjacent)
             if lab == prev:
@@ -46,7 +62,10 @@ class Amplicon:
             prev, run = lab, 1
         if prev is not None:
             out.append(prev if run == 1 else f"{prev}({run})")
-        return ";".join(out)
+        text = ";".join(out)
+        if len(_LABEL_STRINGS) < 100_000:       # few distinct label lists recur over millions of rows
+            _LABEL_STRINGS[key] = text
+        return text
 
     def line(self):
         """merged-file line, Amplicon.py:330-348."""
@@ -63,31 +82,45 @@ def groups_from_records(records, labels, L, D, R, rna=False):
     ConservedEndAmplicons.add() preserves (Amplicon.py:448-481)."""
     if len(records) == 0:
         return []
-    rec = np.sort(records, order=["key", "genome"])
+    # records ordered by (key, rank of the genome's label): every Amplicon's label list is then born
+    # sorted (lexsort on columns is ~2x a structured sort)
+    by_name = np.argsort(np.array(labels, dtype=object), kind="stable")
+    label_rank = np.empty(len(labels), dtype=np.int64)
+    label_rank[by_name] = np.arange(len(labels))
+    order = np.lexsort((label_rank[records["genome"].astype(np.int64)], records["key"]))
+    keys = records["key"][order]
+    genome = records["genome"][order]
+    count = records["count"][order]
     pm = codec.prefix_mask(L, R)
-    keys = rec["key"]
-    new_key = np.ones(len(rec), dtype=bool)
+    new_key = np.ones(len(keys), dtype=bool)
     new_key[1:] = keys[1:] != keys[:-1]
     pre = keys & pm
-    new_group = np.ones(len(rec), dtype=bool)
+    new_group = np.ones(len(keys), dtype=bool)
     new_group[1:] = pre[1:] != pre[:-1]
     # decode every distinct key once, as one byte block of rows left|right|diag
     k = L + D + R
-    text = codec.keys_to_matrix(keys[new_key], L, D, R, rna).tobytes().decode("ascii")
-    groups, amp, row = [], None, 0
-    for nk, ng, gi, cnt in zip(new_key.tolist(), new_group.tolist(), rec["genome"].tolist(),
-                               rec["count"].tolist()):
-        if nk:
+    first = np.flatnonzero(new_key)
+    text = codec.keys_to_matrix(keys[first], L, D, R, rna).tobytes().decode("ascii")
+    # one label per k-mer occurrence, in record order; [lo, hi) of every distinct key in that list
+    ends = np.cumsum(count.astype(np.int64))
+    if int(count.max()) == 1:
+        occ = [labels[g] for g in genome.tolist()]
+    else:
+        occ = [labels[g] for g, c in zip(genome.tolist(), count.tolist()) for _ in range(c)]
+    lo = np.concatenate([[0], ends[first[1:] - 1]]).tolist()
+    hi = np.concatenate([ends[first[1:] - 1], [ends[-1]]]).tolist()
+    groups = []
+    gc_was_on = gc.isenabled()
+    gc.disable()          # millions of small acyclic objects: generational collections only rescan them
+    try:
+        for row, (ng, a, b) in enumerate(zip(new_group[first].tolist(), lo, hi)):
             s = text[row * k:(row + 1) * k]
-            row += 1
-            amp = Amplicon(s[:L], s[L + R:], s[L:L + R], ())
             if ng:
                 groups.append([])
-            groups[-1].append(amp)
-        amp.labels.extend([labels[gi]] * cnt)
-    for g in groups:
-        for a in g:
-            a.labels.sort()
+            groups[-1].append(Amplicon.presorted(s[:L], s[L + R:], s[L:L + R], occ[a:b]))
+    finally:
+        if gc_was_on:
+            gc.enable()
     return groups
 
 
@@ -119,18 +152,18 @@ def bracket_line(group, ingroup):
     return "".join(br)
 
 
-_PLAIN_BASES = frozenset("ACGTU")
+_NOT_PLAIN = {ord(c): None for c in "ACGTU"}      # str.translate table: what is left is not a plain base
 
 
 def collapse_to_iupac(seqs):
     """Amplicon.py:42-66."""
+    first = seqs[0] if seqs else None
+    if first is not None and seqs.count(first) == len(seqs) and not first.translate(_NOT_PLAIN):
+        return first              # one plain sequence: every column is its own consensus
     lens = [len(s) for s in seqs]
     width = max(lens)
     if len(set(lens)) != 1:
         return "-" * width
-    first = seqs[0]
-    if _PLAIN_BASES.issuperset(first) and all(s == first for s in seqs):
-        return first              # one plain sequence: every column is its own consensus
     out = []
     for i in range(width):
         col = {s[i] for s in seqs}
@@ -176,9 +209,15 @@ def render(groups, ingroup_labels, dot=False):
     ingroup = None if ingroup_labels is None else frozenset(ingroup_labels)
     csv = [CSV_HEADER]
     blocks = []
-    for g in groups:
-        blocks.append(render_alignment(g, ingroup, dot) + "\n")
-        csv.append(render_csv_row(g, ingroup))
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        for g in groups:
+            blocks.append(render_alignment(g, ingroup, dot) + "\n")
+            csv.append(render_csv_row(g, ingroup))
+    finally:
+        if gc_was_on:
+            gc.enable()
     return "\n".join(csv) + "\n", "".join(blocks)
 
 
