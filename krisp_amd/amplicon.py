@@ -212,7 +212,27 @@ def render(groups, ingroup_labels, dot=False):
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
+        brackets = {}
         for g in groups:
+            if ingroup is None and len(g) == 1:
+                # the bulk of a large result (conserved regions, no outgroup): one sequence, no
+                # variable column -- the same text as the general path below, without its calls
+                a = g[0]
+                seq = a.left + a.diag + a.right
+                line = seq + " : " + a.label_string()
+                if dot:
+                    blocks.append(line + "\n\n")
+                else:
+                    shape = (len(a.left), len(a.diag))
+                    br = brackets.get(shape)
+                    if br is None:
+                        br = brackets[shape] = " " * (shape[0] - 1) + "{" + "-" * shape[1] + "}"
+                    blocks.append(line + "\n" + br + "\n\n")
+                if not seq.translate(_NOT_PLAIN):
+                    csv.append(a.left + "," + a.diag + "," + a.right)
+                else:
+                    csv.append(render_csv_row(g, ingroup))
+                continue
             blocks.append(render_alignment(g, ingroup, dot) + "\n")
             csv.append(render_csv_row(g, ingroup))
     finally:

@@ -342,3 +342,23 @@ def test_render_from_wide_hits_matches_reference_text(case, tmp_path):
     assert align == case["align"]
     want = case["filtered_canon"] if "filtered_canon" in case else case["merged_canon"]
     assert sorted(amplicon.merged_lines(groups)) == want
+
+
+def test_render_fast_path_equals_the_general_path():
+    """amplicon.render shortcuts groups of one sequence when there is no outgroup (the bulk of a
+    large result); the shortcut must print what the general functions print"""
+    import random
+    rng = random.Random(1)
+    groups = []
+    for _ in range(3000):
+        L, D, R = rng.randint(0, 6), rng.randint(0, 4), rng.randint(0, 5)
+        if L + D + R == 0:
+            L = 1
+
+        def mk(n):
+            return "".join(rng.choice("ACGTN" if rng.random() < 0.1 else "ACGT") for _ in range(n))
+        groups.append([amplicon.Amplicon(mk(L), mk(D), mk(R), [rng.choice("abc") for _ in range(rng.randint(1, 4))])])
+    for dot in (False, True):
+        csv, aln = amplicon.render(groups, None, dot)
+        assert csv == "\n".join([amplicon.CSV_HEADER] + [amplicon.render_csv_row(g, None) for g in groups]) + "\n"
+        assert aln == "".join(amplicon.render_alignment(g, None, dot) + "\n" for g in groups)
