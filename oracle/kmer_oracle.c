@@ -4,7 +4,7 @@
  * (grunwaldlab/krisp @ 2024_10_08) on 2-bit packed k-mers, used (a) by the
  * `-m gpu` parity tests as the checker at sizes the text-level oracle
  * (oracle/krisp_oracle.py) cannot reach, (b) by bench.py's cpu_baseline leg
- * (kind "port", 1 thread).  krisp_amd/ never links or loads it.
+ * (kind "port"; one genome per thread, up to 4).  krisp_amd/ never links or loads it.
  *
  * Parity status: PINNED through tests/test_kmer_oracle.py, which converts these
  * integer results back to the reference's text lines and compares them with
