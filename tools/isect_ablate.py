@@ -15,6 +15,9 @@ with _native.Engine() as eng:
     flags = np.array([1 if f else 0 for _, f, _ in fam], dtype=np.uint8)
     n = sum(eng.count(i) for i in range(len(fam)))
     for mode, what in ((0, "full"), (64, "keys streamed, no probes"), (128, "probes, no LDS update"),
-                       (512, "anchor work only (no streaming)"), (0, "full")):
+                       (512, "anchor work only (no streaming)"),
+                       (512 + 1024, "anchor only, no own masks"), (512 + 2048, "anchor only, no survivors pass"),
+                       (512 + 4096, "anchor only, no sub-bin table"), (512 + 1024 + 2048 + 4096, "anchor only, none of the three"),
+                       (0, "full")):
         ms = eng.lib.kr_debug_intersect(eng.ctx, _native._ptr(ids), len(ids), _native._ptr(flags), 10, mode)
         print(f"{what:32s} {ms:.3f} ms  {8 * n / ms / 1e6:.0f} GB/s", flush=True)
