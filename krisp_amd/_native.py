@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkrisp_hip.so")
+# KRISP_HIP_LIB: another build of the same library (A/B variants of tools/ab.sh); the product file
+# is never overwritten by a variant
+LIB_PATH = os.environ.get("KRISP_HIP_LIB") or os.path.join(HERE, "libkrisp_hip.so")
 
 CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
@@ -23,9 +25,9 @@ STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
           "fallback", "intersect", "compact", "collect", "merge", "locate"]
 # stage -> the kernel(s) it times (names as rocprofv3 prints them)
-STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1",
-                 "hist2": "k_hist16 (or k_hist2)", "scan2": "k_hist16_off (or k_scan2)", "scatter2": "k_scatter2",
-                 "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort",
+STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1p",
+                 "hist2": "k_hist16 (or k_hist2)", "scan2": "k_hist16_off (or k_scan2)", "scatter2": "k_scatter2p",
+                 "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort2",
                  "fallback": "k_bitonic_stage", "intersect": "k_intersect", "compact": "k_scan+k_gather_cands",
                  "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact",
                  "locate": "k_wide_locate"}

@@ -22,6 +22,7 @@
 // One translation unit, cut into parts by subject (kernels k_*, host code h_*):
 #include "k_keys.inc"        // typedefs, key geometry, tunables, key generators
 #include "k_sort.inc"        // pack, histograms, pass 0 / 1 / 2, chunk table, LDS sort, merge fallback
+#include "k_sort2.inc"       // pass 1 / pass 2 / LDS sort as persistent, software-pipelined kernels (buffer loads, counted waits)
 #include "k_intersect.inc"   // n-way intersection, candidate compaction, collection, list merge
 #include "k_wide.inc"        // wide path kernels, copy kernel
 

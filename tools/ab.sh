@@ -2,13 +2,13 @@
 # A/B of build variants inside ONE gpurun call (boxes differ by up to 10 %, so variants must be
 # compared on the same box, interleaved).  Build the variants first, here, with tools/ab_build.sh;
 # then: gpurun -- 'bash tools/ab.sh base varA varB'.  A variant that fails the quick parity
-# subset is not benchmarked.
+# subset is not benchmarked.  Variants are selected with KRISP_HIP_LIB (krisp_amd/_native.py):
+# the product library is never overwritten.
 ROOT=$(pwd)
-LIB=$ROOT/krisp_amd/libkrisp_hip.so
-cp "$LIB" /tmp/orig.so
+mkdir -p "$ROOT/gpurun_out"
 OK=""
 for v in "$@"; do
-  cp "$ROOT/krisp_amd/variants/$v.so" "$LIB"
+  export KRISP_HIP_LIB="$ROOT/krisp_amd/variants/$v.so"
   if timeout -k 10 300 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu > "$ROOT/gpurun_out/ab_$v.test.log" 2>&1; then
     OK="$OK $v"
   else
@@ -17,7 +17,7 @@ for v in "$@"; do
 done
 for round in 1 2 3; do
   for v in $OK; do
-    cp "$ROOT/krisp_amd/variants/$v.so" "$LIB"
+    export KRISP_HIP_LIB="$ROOT/krisp_amd/variants/$v.so"
     timeout -k 10 120 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$ROOT/gpurun_out/ab_$v.$round.json" 2>/dev/null || { echo "bench of $v failed"; continue; }
     python3 - "$v" "$round" "$ROOT/gpurun_out/ab_$v.$round.json" <<'PY'
 import json, sys
@@ -28,4 +28,4 @@ print(sys.argv[1], "round", sys.argv[2], "ms/step %.3f" % d["ms_per_step"], "G/s
 PY
   done
 done
-cp /tmp/orig.so "$LIB"
+unset KRISP_HIP_LIB
