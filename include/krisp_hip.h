@@ -65,7 +65,10 @@ enum {
     KR_ERR_HIP = -1,       /* a HIP runtime call failed */
     KR_ERR_PARAM = -2,     /* bad argument (k > 32, D > 16, unknown genome id ...) */
     KR_ERR_CAPACITY = -3,  /* caller buffer too small / hbm budget exceeded */
-    KR_ERR_STATE = -4      /* call sequence error (e.g. intersect before sort) */
+    KR_ERR_STATE = -4,     /* call sequence error (e.g. intersect before sort) */
+    KR_ERR_KEY = -5,       /* kr_scan_special: a surviving window holds a character outside the reference's
+                              COMP_MAP -- the reference raises KeyError there (kstream.py:658) */
+    KR_ERR_HOST = -6       /* kr_scan_special: bytes >= 0x80 in a candidate window, left to the host layer */
 };
 
 enum { KR_SOFT_MAP = 0,    /* lower case -> upper case (krisp_fasta default, krisp_fasta.py:33-43) */
@@ -127,7 +130,7 @@ int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
 
 /* ---- wide windows: amplicons longer than one 64-bit key (L+D+R > 32, or D > 16) ------------
  * The reference has no length limit (its k-mers are text: krisp_fasta.py:21-43 passes any
- * kmers= / split= to kstream, tests/krisp_fasta/test.sh runs 32/60/32).  Here `left` and `right`
+ * kmers= / split= to kstream, README.md:201-232 runs --conserved 30 --amplicon 100).  Here `left` and `right`
  * still fit one key each (1 <= L, R <= 32) and L+D+R <= KR_WIDE_MAX_K.  The library sorts and
  * intersects three times with the 64-bit pipeline (the `left` spectrum, the `right` spectrum,
  * then exact composite keys rank(left):rank(right)), applies the diagnostic filter
@@ -161,6 +164,26 @@ int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* retu
 int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines, int one_shot, uint8_t* out,
                           size_t cap, int64_t* stats);
 
+/* Host-side (no GPU involved): the side channel of SURVEY 8(b) -- the windows the device's 2-bit
+ * alphabet cannot carry.  `bases` is an upload buffer (kr_fasta_to_bases).  Returns the number of
+ * window starts (ascending) of windows of k characters that survive the soft-mask rule, hold no
+ * N/n and hold an IUPAC ambiguity letter: the reference keeps those k-mers and complements them
+ * letter by letter (COMP_MAP kstream.py:11-18, _complements 644-677); the binder cuts them out
+ * of its text and joins them with the device results.  KR_ERR_KEY (+ *bad_char) where the
+ * reference raises KeyError (kstream.py:658).  starts may be NULL (count only). */
+int64_t kr_scan_special(const uint8_t* bases, size_t n, int k, int omit_soft, uint64_t* starts, size_t cap,
+                        int* bad_char);
+
+/* Options that change HOW (never what) the library computes; results are identical for every
+ * value (tests run the suite under each).  Set after kr_create, before kr_set_params. */
+enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in 4^n key-space slices (the
+                                        large-genome path, pass 0 + per-slice pass 1) */
+       KR_OPT_GENERIC_INTERSECT = 2, /* 1: every intersect sub-tile takes the generic path (key-count
+                                        splits, ranges from the prefixes) instead of whole-bucket sub-tiles */
+       KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4 */
+       KR_OPT_ABLATE = 4 };          /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
+int     kr_set_option(kr_ctx*, int option, int64_t value);
+
 int     kr_sync(kr_ctx*);
 /* HIP-event timers on the context's stream */
 int     kr_timer_begin(kr_ctx*);
@@ -182,11 +205,11 @@ int64_t kr_stage_launches(kr_ctx*, int stage);
 int64_t kr_debug_fetch(kr_ctx*, int genome_id, int what, void* out, size_t cap_bytes);
 /* property check for sizes no oracle reaches: adjacent key pairs out of order (0 = sorted) */
 int64_t kr_debug_inversions(kr_ctx*, int genome_id);
-/* timing aid: k_localsort re-run `reps` times over a sorted genome; mode 0 = as shipped,
- * 64 = load + store only, 128 = without the ranking step.  Average ms per launch. */
+/* timing aid: the LDS sort re-run `reps` times over a sorted genome (mode must be 0).  Average ms per launch. */
 double  kr_debug_localsort(kr_ctx*, int genome_id, int reps, int mode);
-/* timing aid: the intersect kernel with parts switched off (mode 0 as shipped, 64 keys streamed
- * but not probed, 128 probed without the LDS update); leaves the candidate set invalid */
+/* timing aid: the intersect kernel `reps` times (mode 0 as shipped; a -DKR_ABLATE build also
+ * takes 64 keys streamed but not probed, 128 probed without the LDS update, ...: k_intersect.inc);
+ * leaves the candidate set invalid */
 double  kr_debug_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup, int reps, int mode);
 /* measured streaming-copy rate of this device (read + write GB/s): bench.py reports the roofline
  * fraction against it beside the 8 TB/s specification figure */

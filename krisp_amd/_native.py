@@ -21,6 +21,8 @@ WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS = 0, 1, 2, 
 WIDE_MAX_K = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
+OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE = 1, 2, 3, 4
+ERR_KEY, ERR_HOST = -5, -6
 STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
           "fallback", "intersect", "compact", "collect", "merge", "locate"]
@@ -59,6 +61,8 @@ SYMBOLS = [
     ("kr_wide_run", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_wide_fetch", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_fasta_to_bases", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
+    ("kr_scan_special", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
+    ("kr_set_option", _c.c_int, [_P, _c.c_int, _c.c_int64]),
     ("kr_sync", _c.c_int, [_P]),
     ("kr_timer_begin", _c.c_int, [_P]),
     ("kr_timer_end_ms", _c.c_double, [_P]),
@@ -119,6 +123,27 @@ def fasta_to_bases(data, universal_newlines, one_shot=True):
     return out[:n], int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
 
 
+def scan_special_starts(bases, k, omit_soft):
+    """Window starts (ascending) of the surviving, N-free windows that hold an IUPAC ambiguity letter
+    (kr_scan_special).  Raises KeyError(char) exactly where the reference does; returns None when the
+    library leaves the case to the host (bytes >= 0x80 near a special character)."""
+    lib = load()
+    buf = np.ascontiguousarray(bases, dtype=np.uint8)
+    bad = ctypes.c_int(0)
+    n = lib.kr_scan_special(_ptr(buf) if len(buf) else None, len(buf), k, 1 if omit_soft else 0, None, 0,
+                            ctypes.byref(bad))
+    if n == ERR_KEY:
+        raise KeyError(chr(bad.value))
+    if n == ERR_HOST:
+        return None
+    if n < 0:
+        raise KrispHipError(f"kr_scan_special: [{n}]")
+    out = np.empty(max(n, 1), dtype=np.uint64)
+    lib.kr_scan_special(_ptr(buf) if len(buf) else None, len(buf), k, 1 if omit_soft else 0, _ptr(out), n,
+                        ctypes.byref(bad))
+    return out[:n]
+
+
 class Engine:
     """One GPU context (one HIP stream) -- thin object face of the C ABI."""
 
@@ -152,6 +177,10 @@ class Engine:
         return rc
 
     # ---- configuration
+    def set_option(self, option, value):
+        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT); before set_params"""
+        self._check(self.lib.kr_set_option(self.ctx, option, int(value)), "kr_set_option")
+
     def set_params(self, L, D, R, omit_soft=False, max_bases=0):
         self._check(self.lib.kr_set_params(self.ctx, L, D, R, SOFT_OMIT if omit_soft else SOFT_MAP,
                                            max_bases), "kr_set_params")

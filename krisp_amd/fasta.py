@@ -146,6 +146,20 @@ def scan_special(bases, k, omit_soft):
     special = np.flatnonzero(~_PLAIN[bases])
     if len(special) == 0:
         return []
+    # the library's scan (kr_scan_special: the C ABI's side channel) finds the windows; the host
+    # only cuts the text.  Bytes >= 0x80 near a special character: Python's own case rules below.
+    from . import _native
+    starts_lib = _native.scan_special_starts(bases, k, omit_soft)
+    if starts_lib is not None:
+        text = bases.tobytes().decode("latin-1")
+        out = []
+        for s in starts_lib.tolist():
+            w = text[s:s + k]
+            if not omit_soft:
+                w = w.upper()
+            out.append(w)
+            out.append(w[::-1].translate(_COMP_TABLE))
+        return out
     text = bases.tobytes().decode("latin-1")
     seps = np.flatnonzero(bases == 10)
     starts = set()

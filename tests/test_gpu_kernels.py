@@ -29,9 +29,11 @@ def _rand_text(seed, n, alphabet=b"ACGT", records=3):
     return t
 
 
-def _check_sorted(N, K, text, L, D, R, omit=False, stages=False):
+def _check_sorted(N, K, text, L, D, R, omit=False, stages=False, slice_bases=None):
     want = K.sorted_keys(text.tobytes(), L, D, R, omit=omit)
     with N.Engine() as e:
+        if slice_bases is not None:
+            e.set_option(N.OPT_SLICE_BASES, slice_bases)
         e.set_params(L, D, R, omit_soft=omit, max_bases=len(text))
         e.upload(0, text)
         e.sort(0)
@@ -138,6 +140,69 @@ def test_sort_skewed_genome_overflow_fallback(N, K):
     text = np.concatenate(parts)
     info = _check_sorted(N, K, text, 25, 1, 2)
     assert info["overflow_segments"] >= 1 and info["fallback_launches"] > 0
+
+
+@pytest.mark.parametrize("sb", [1, 2])
+@pytest.mark.parametrize("n,L,D,R,omit", [(300_000, 25, 1, 2, False), (2_500_000, 6, 2, 4, False),
+                                          (1_200_000, 28, 1, 2, True), (40_000, 3, 1, 2, False),
+                                          (700_000, 12, 4, 12, False), (64, 25, 1, 2, False)])
+def test_sort_in_key_space_slices_vs_oracle(N, K, sb, n, L, D, R, omit):
+    """the large-genome path at test sizes: KR_OPT_SLICE_BASES forces 4^sb key-space slices (pass 0
+    over all keys, then per slice a pass 1 from the pass-0 array, pass 2, LDS sort); the fetched
+    keys equal the packed oracle's"""
+    text = _rand_text(300 + n % 89 + sb, n, alphabet=b"ACGTACGTACGTACGTNacgt", records=7)
+    info = _check_sorted(N, K, text, L, D, R, omit=omit, slice_bases=sb)
+    assert info["nslices"] == 4 ** min(sb, L)
+
+
+@pytest.mark.parametrize("sb,generic,fmt", [(1, 0, 0), (2, 0, 0), (0, 1, 0), (0, 0, 1), (2, 1, 1)])
+@pytest.mark.parametrize("L,D,R,length,n", [(25, 1, 2, 200_000, 4), (12, 4, 12, 100_000, 3), (8, 1, 4, 20_000, 5)])
+def test_intersect_and_collect_under_every_option(N, K, sb, generic, fmt, L, D, R, length, n):
+    """the result-neutral options of kr_set_option (key-space slices, generic intersect sub-tiles,
+    narrow per-prefix state): candidates, masks and records equal the packed oracle's under each"""
+    fam = _family(L + D + R + sb, n, length)
+    flags = [f for _, f, _ in fam]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
+    with N.Engine() as e:
+        e.set_option(N.OPT_SLICE_BASES, sb)
+        e.set_option(N.OPT_GENERIC_INTERSECT, generic)
+        e.set_option(N.OPT_ISECT_FORMAT, fmt)
+        e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        assert e.debug_info()["nslices"] == 4 ** min(sb, L)
+        for i, (_, _, t) in enumerate(fam):
+            assert e.add(i, t) == len(want_keys[i])
+            assert np.array_equal(e.keys(i), want_keys[i])
+        for filt in (False, True):
+            want = K.intersect(want_keys, flags, L, D, R, apply_filter=filt)
+            assert e.intersect(list(range(n)), flags, apply_filter=filt) == len(want)
+            got = e.cands()
+            for f in ("prefix", "in_mask", "out_mask"):
+                assert np.array_equal(got[f], want[f]), f
+            recs = np.sort(e.collect(list(range(n))), order=["key", "genome"])
+            wrec = np.sort(K.collect(want_keys, want, L, D, R), order=["key", "genome"])
+            assert np.array_equal(recs, wrec)
+
+
+def test_options_are_checked(N, monkeypatch):
+    """kr_set_option: bad values, bad order and the ablation switch of a regular build are refused;
+    KR_DBG in the environment reaches only its documented, result-neutral bit"""
+    monkeypatch.setenv("KR_DBG", str(64 | 128 | 512))      # round-1 ablation bits: must be ignored
+    with N.Engine() as e:
+        with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_SLICE_BASES, 5)
+        with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_ISECT_FORMAT, 2)
+        with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_ABLATE, 64)
+        with pytest.raises(N.KrispHipError):
+            e.set_option(99, 0)
+        text = _rand_text(5, 100_000, b"ACGT", records=2)
+        e.set_params(25, 1, 2, max_bases=len(text))
+        e.upload(0, text)
+        with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_SLICE_BASES, 1)             # after an upload
+        e.sort(0)
+        assert e.inversions(0) == 0                          # (KR_DBG=64 used to skip the sort)
 
 
 def test_key_space_slices_report(N):

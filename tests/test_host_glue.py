@@ -362,3 +362,41 @@ def test_render_fast_path_equals_the_general_path():
         csv, aln = amplicon.render(groups, None, dot)
         assert csv == "\n".join([amplicon.CSV_HEADER] + [amplicon.render_csv_row(g, None) for g in groups]) + "\n"
         assert aln == "".join(amplicon.render_alignment(g, None, dot) + "\n" for g in groups)
+
+
+def test_scan_special_through_the_abi_equals_the_python_scan():
+    """kr_scan_special (the C ABI's side channel for windows the 2-bit alphabet cannot carry) against
+    the pure-Python scan on random texts: same IUPAC k-mers, same KeyError character"""
+    import random
+    from krisp_amd import _native, fasta
+
+    def py_scan(b, k, omit):
+        orig = _native.scan_special_starts
+        _native.scan_special_starts = lambda *a: None        # force the host loop
+        try:
+            return fasta.scan_special(b, k, omit)
+        finally:
+            _native.scan_special_starts = orig
+
+    rng = random.Random(7)
+    alph = "ACGTACGTACGTacgtNnRYMKSWBVDHrymkXx-.\n"
+    seen_key = seen_iupac = 0
+    for _ in range(1500):
+        t = "".join(rng.choice(alph) for _ in range(rng.randint(0, 120))).encode()
+        b = np.frombuffer(t, dtype=np.uint8)
+        k, omit = rng.randint(1, 12), rng.random() < 0.5
+        try:
+            want = ("ok", py_scan(b, k, omit))
+        except KeyError as e:
+            want = ("key", e.args[0])
+        try:
+            got = ("ok", fasta.scan_special(b, k, omit))
+        except KeyError as e:
+            got = ("key", e.args[0])
+        assert got == want, (t, k, omit)
+        seen_key += want[0] == "key"
+        seen_iupac += want[0] == "ok" and len(want[1]) > 0
+    assert seen_key > 50 and seen_iupac > 50
+    # bytes >= 0x80 are left to the host layer
+    b = np.frombuffer("ACGR\xe9ACGT".encode("latin-1"), dtype=np.uint8)
+    assert _native.scan_special_starts(b, 3, False) is None
