@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers/s sorted + intersected (BASELINE.json metric) on MI355X.
 
-A "step" = one pass of the hot path over one batch of synthetic genomes that are
-already resident in HBM as ASCII bases: per genome pack -> both-strand keys ->
-MSD radix partition -> LDS sort, then the n-way intersection + diagnostic
-filter.  At N = 1 the workload is BASELINE.json configs[1]: 4 synthetic 50 Mbp
-genomes (2 in / 2 out), k = 28 as 25/1/2.  At N > 1 every rank gets its own 4
-genomes of one 4N-genome family (weak scaling; SURVEY.md 8e, configs[3] style):
-sort + local intersect per GPU, then ONE exchange -- a binary-tree reduction of
-candidate lists over RCCL -- and the filter on rank 0.
+A "step" = one pass of the hot path over one batch of synthetic genomes that are already
+resident in HBM as ASCII bases: per genome pack -> both-strand keys -> MSD radix partition ->
+LDS sort, then the n-way intersection + diagnostic filter and the collection of the candidate
+records -- SURVEY 8(d): "from packed bases resident in HBM to filtered candidate records
+resident in HBM".  At N = 1 the default workload is BASELINE.json configs[1]: 4 synthetic 50 Mbp
+genomes (2 in / 2 out), k = 28 as 25/1/2.  At N > 1 every rank gets its own 4 genomes of one
+4N-genome family (weak scaling; SURVEY.md 8e, configs[3] style): sort + local intersect per GPU,
+then ONE exchange -- a binary-tree reduction of candidate lists between the GPUs (RCCL, inside
+the library: csrc/h_comm.inc) -- the survivors broadcast and every rank collects its records.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).  After the W warm-up
-steps come 3 untimed calibration steps with every kernel stage bracketed by HIP events (the stage
-table, the dominant kernel); the K timed steps bracket the dominant kernel's launches only.
+The launcher only starts the processes (RANK / LOCAL_RANK / WORLD_SIZE): nothing here imports
+torch.  Barrier = stream sync + a reduction over all ranks (kr_comm_barrier); the step time is the
+MAX over ranks (kr_comm_allreduce).  Rank 0 prints ONE JSON line (DESIGN.md "Measurement").
+After the W warm-up steps come 3 untimed calibration steps with every kernel stage bracketed by
+HIP events (the stage table, the dominant kernel); the K timed steps bracket the dominant kernel's
+launches only.
 """
 import argparse
 import json
@@ -27,8 +31,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MODEL_BYTES_PER_KMER = 136.5    # 0.5 + W + W + 2*W*P + W at W = 8, P = 7 (k = 28)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy there)
+
+
+def model_bytes_per_kmer(k):
+    """B = 0.5 + W + W + 2 W P + W with W = 8-byte keys, P = ceil(2 k / 8) LSD passes"""
+    return 0.5 + 8 + 8 + 2 * 8 * -(-2 * k // 8) + 8
+
 
 # ALGORITHMIC bytes per k-mer record of each kernel stage (DESIGN.md "kernels"):
 # the stage's share of SURVEY 8(d)'s model -- bases in, key write, pass read+write, intersect read.
@@ -41,6 +50,31 @@ STAGE_BYTES = {
     "localsort": 16.0,              # key in, key out
     "intersect": 8.0,               # every key of every genome read once
 }
+
+# the reference itself, timed in the build container (8 vCPU Xeon 2.1 GHz,
+# GNU sort 8.32): NOT on the GPU box, carried here so that the line names what the Python did
+REFERENCE_PYTHON = {"value": 1.04e5, "unit": "k-mers/s", "cores": 8,
+                    "what": "reference krisp_fasta (--cores 8 equivalent) on 4 x 1 Mbp of the same generator: 77.1 s "
+                            "for 8.00e6 k-mers (extract+sort 12.9 s, merge 57.7 s, filter 6.5 s)",
+                    "where": "SURVEY.md section 6, measured in the build container (8 vCPU Intel Xeon 2.1 GHz), "
+                             "not on the GPU box: the reference cannot travel there"}
+
+
+def baseline_config_name(world, per_gpu, length, ldr, independent, masked):
+    """which BASELINE.json config the arguments are (or "custom")"""
+    L, D, R = ldr
+    plain = not independent and not masked
+    if plain and world == 1 and per_gpu == 4 and length == 50_000_000 and ldr == [25, 1, 2]:
+        return "BASELINE configs[1]"
+    if plain and world == 8 and per_gpu == 4 and length == 100_000_000 and ldr == [25, 1, 2]:
+        return "BASELINE configs[3]"
+    if plain and world == 1 and per_gpu == 2 and length == 3_000_000_000 and ldr == [28, 1, 2]:
+        return "BASELINE configs[4]"
+    if plain and per_gpu == 4 and length == 50_000_000 and ldr == [25, 1, 2]:
+        return f"BASELINE configs[1] per GPU, weak-scaled to {world} GPUs"
+    if world == 1 and per_gpu == 4 and length == 50_000_000 and ldr == [25, 1, 2]:
+        return "BASELINE configs[1] geometry, SURVEY 8(d) secondary input"
+    return "custom (not a BASELINE.json config)"
 
 
 def make_genomes(config, rank, world, per_rank, length, independent=False, masked=False):
@@ -59,33 +93,75 @@ def make_genomes(config, rank, world, per_rank, length, independent=False, maske
     return out
 
 
-def cpu_baseline(config, L, D, R, length, full_length):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(config, L, D, R, length, full_length, per_gpu):
     """The packed-key C oracle (oracle/kmer_oracle.c) on a bounded sample of the same workload:
     same generator and parameters, genomes shortened so that the run takes roughly 10-20 s on
-    this host (calibrated on 4 x 1 Mbp first).  One thread per genome for the sorts -- the
+    this host (calibrated on 1 Mbp genomes first).  One thread per genome for the sorts -- the
     reference's own parallelism, a process per genome (krisp_fasta.py:86-123) -- then the n-way
-    intersection on one thread."""
+    intersection + filter + collect on one thread; `replicas` such families run side by side so
+    that all host cores work (cores = threads actually used).  Also the reference's own
+    CPU-runnable case, BASELINE configs[0] (test_data/krisp_fasta, 9.8e4 k-mers), end to end."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import kmer_oracle as K
     K.build()
-    cores = max(1, min(4, os.cpu_count() or 1))
+    # the host cores this process may use: its affinity mask, capped at the one-GPU share of a box
+    # (16 cores per GPU on the benchmark pool; KRISP_BENCH_CPU_THREADS overrides)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, int(os.environ.get("KRISP_BENCH_CPU_THREADS", "16"))))
+    replicas = max(1, ncpu // per_gpu)
+    cores = min(ncpu, replicas * per_gpu)
 
-    def run(fam):
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as pool:       # ctypes releases the GIL
+    def one_family(fam):
+        with ThreadPoolExecutor(max_workers=per_gpu) as pool:       # ctypes releases the GIL
             keys = list(pool.map(lambda g: K.sorted_keys(g[2].tobytes(), L, D, R), fam))
-        K.intersect(keys, [f for _, f, _ in fam], L, D, R, apply_filter=True)
-        return time.perf_counter() - t0, sum(len(k) for k in keys)
+        cands = K.intersect(keys, [f for _, f, _ in fam], L, D, R, apply_filter=True)
+        K.collect(keys, cands, L, D, R)
+        return sum(len(k) for k in keys)
+
+    def run(fam, reps):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=reps) as pool:
+            n = sum(pool.map(lambda _: one_family(fam), range(reps)))
+        return time.perf_counter() - t0, n
 
     if length <= 0:
-        per_mbp = run(make_genomes(config, 0, 1, 4, 1_000_000))[0] / 4.0
-        length = int(min(full_length, max(1_000_000, 15.0 / (4.0 * per_mbp) * 1e6)))
+        per_mbp = run(make_genomes(config, 0, 1, per_gpu, 1_000_000), replicas)[0] / per_gpu
+        length = int(min(full_length, max(1_000_000, 15.0 / (per_gpu * per_mbp) * 1e6)))
         length -= length % 1_000_000
-    dt, n = run(make_genomes(config, 0, 1, 4, length))
-    return {"value": n / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": f"4 x {length / 1e6:g} Mbp genomes of the same generator, {L}/{D}/{R}, "
-                      f"{n} k-mers in {dt:.1f} s (oracle/kmer_oracle.c: generate + LSD radix sort per genome on "
-                      f"{cores} threads, then n-way intersect + filter on one)"}
+    dt, n = run(make_genomes(config, 0, 1, per_gpu, length), replicas)
+    out = {"value": n / dt, "unit": "k-mers/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+           "sample": f"{replicas} side-by-side replica(s) of {per_gpu} x {length / 1e6:g} Mbp genomes of the same "
+                     f"generator, {L}/{D}/{R}, {n} k-mers in {dt:.1f} s (oracle/kmer_oracle.c: generate + LSD radix "
+                     f"sort, one thread per genome; n-way intersect + filter + collect on one thread per replica)",
+           "reference_python": REFERENCE_PYTHON}
+    # BASELINE configs[0]: the reference's test data through the same oracle (file text -> records)
+    try:
+        from krisp_amd import fasta
+        d = os.path.join(ROOT, "tests", "golden", "c1")
+        files = [(f"{d}/ingroup{i}.fasta.gz", True) for i in (0, 1)] + [(f"{d}/outgroup{i}.fasta.gz", False) for i in (0, 1, 2)]
+        t0 = time.perf_counter()
+        keys = [K.sorted_keys(fasta.to_bases(fasta.read_records(f)).tobytes(), 25, 1, 2) for f, _ in files]
+        c = K.intersect(keys, [f for _, f in files], 25, 1, 2, apply_filter=True)
+        K.collect(keys, c, 25, 1, 2)
+        dt1 = time.perf_counter() - t0
+        out["configs0_test_data"] = {"kmers": int(sum(len(k) for k in keys)), "seconds": round(dt1, 4),
+                                     "candidates": int(len(c)), "what": "test_data/krisp_fasta 25/1/2 through the oracle, one thread"}
+    except Exception as e:  # noqa: BLE001
+        out["configs0_test_data"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -102,42 +178,33 @@ def main():
                     help="bases per genome of the CPU baseline sample (0 = calibrate to ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: rehearse the N > 1 flow with several ranks sharing the visible GPU(s)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (nccl) even at world size 1 (plumbing self-test)")
+    ap.add_argument("--no-collect", action="store_true", help="leave kr_collect out of the step (round-1 definition)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "dir"],
+                    help="dir: rehearse the N > 1 flow with several ranks sharing the visible GPU (messages through files)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="create the RCCL communicator even at world size 1 (plumbing self-test)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from krisp_amd import _native
+    from krisp_amd import distributed as D
+    rank, local_rank, world = D.env_rank_world()
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
+    if args.transport == "dir":
+        local_rank = 0                          # rehearsal: the ranks share the GPU
 
-    from krisp_amd import _native
-    dist = None
-    device = None
-    if world > 1 or args.force_dist:
-        import torch
-        import torch.distributed as dist
-        if args.dist_backend == "gloo":            # rehearsal: ranks share the GPU(s), lists travel over gloo
-            local_rank %= max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            device = torch.device("cuda", local_rank)
-    from krisp_amd.distributed import tree_reduce_candidates
-
-    L, D, R = args.ldr
+    L, Dg, R = args.ldr
+    k = L + Dg + R
     config = 2
     genomes = make_genomes(config, rank, world, args.per_gpu, args.length, args.independent, args.masked)
     eng = _native.Engine(device=local_rank)
-    eng.set_params(L, D, R, omit_soft=False, max_bases=max(len(t) for _, _, t in genomes))
+    comm = world > 1 or args.force_comm
+    if comm:
+        D.connect(eng, rank, world, transport=args.transport)
+    eng.set_params(L, Dg, R, omit_soft=False, max_bases=max(len(t) for _, _, t in genomes))
     ids = []
     for g, ing, text in genomes:
         eng.upload(g, text)            # inputs resident in HBM before the timed region
@@ -146,18 +213,24 @@ def main():
     del genomes
 
     def barrier():
-        eng.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
+        if comm:
+            eng.comm_barrier()         # stream sync, then every rank meets
+        else:
+            eng.sync()
+
+    nrec = [0]
 
     def step():
         for g in ids:
             eng.sort(g)
-        if world == 1:
-            return eng.intersect(ids, flags, apply_filter=True)
-        eng.intersect(ids, flags, apply_filter=True)     # safe local pruning (monotone predicate)
-        return tree_reduce_candidates(eng, dist, rank, world, apply_filter=True, device=device)
+        n = eng.intersect(ids, flags, apply_filter=True)     # (N > 1: safe local pruning, the predicate is monotone)
+        if world > 1:
+            n = eng.cands_reduce(apply_filter=True)
+            if not args.no_collect:
+                eng.cands_bcast()
+        if not args.no_collect:
+            nrec[0] = eng.collect(ids, fetch=False)          # the records stay in HBM
+        return n
 
     for _ in range(args.warmup):
         step()
@@ -187,21 +260,19 @@ def main():
     dt = time.perf_counter() - t0
     stages = eng.stage_times() if not args.no_stage_timers else {}
     kmers_local = sum(eng.count(g) for g in ids)
-    copy_gbps = eng.copy_gbps(1 << 30, 10) if rank == 0 else None      # measured streaming-copy peak of this box
+    copy_gbps = eng.copy_gbps(1 << 30, 10) if rank == 0 else None      # measured streaming-copy rate of this box
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        k = torch.tensor([kmers_local], dtype=torch.int64, device=device if device is not None else "cpu")
-        dist.all_reduce(k, op=dist.ReduceOp.SUM)
-        kmers_total = int(k.item())
+    if comm and world > 1:
+        dt = float(eng.comm_allreduce([dt], "max")[0])
+        kmers_total = int(eng.comm_allreduce([float(kmers_local)], "sum")[0])
+        records_total = int(eng.comm_allreduce([float(nrec[0])], "sum")[0])
     else:
-        kmers_total = kmers_local
+        kmers_total, records_total = kmers_local, nrec[0]
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = kmers_total * args.steps / dt
+        model_b = model_bytes_per_kmer(k)
         # dominant kernel stage of this rank (HIP events on the engine's stream)
         roof = None
         if stages:
@@ -223,7 +294,7 @@ def main():
             # the default workload only; expressed like `achieved`: bytes per launch / launch time
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile) and args.length == 50_000_000 and args.per_gpu == 4 and [L, D, R] == [25, 1, 2]:
+            if os.path.exists(tfile) and args.length == 50_000_000 and args.per_gpu == 4 and [L, Dg, R] == [25, 1, 2]:
                 try:
                     tb = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
                     traffic = round(tb / (avg_ms * 1e-3) / 1e9, 1) if tb else None
@@ -232,35 +303,41 @@ def main():
             roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(achieved / copy_gbps, 4),
+                    "copy_peak_guide": 6290.0,
                     "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                    "pipeline_model_GBps": round(MODEL_BYTES_PER_KMER * value / world / 1e9, 1),
-                    "pipeline_model_frac": round(MODEL_BYTES_PER_KMER * value / world / 1e9 / HBM_PEAK_GBPS, 4),
+                    "pipeline_model_bytes_per_kmer": model_b,
+                    "pipeline_model_GBps": round(model_b * value / world / 1e9, 1),
+                    "pipeline_model_frac": round(model_b * value / world / 1e9 / HBM_PEAK_GBPS, 4),
                     "stage_ms_per_step_calibration": {s: round(v[0], 4) for s, v in calib.items()}}
+        name = baseline_config_name(world, args.per_gpu, args.length, [L, Dg, R], args.independent, args.masked)
         out = {
-            "metric": "k-mers/s sorted+intersected at k=28", "value": value, "unit": "k-mers/s",
+            "metric": f"k-mers/s sorted+intersected at k={k}", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.per_gpu} synthetic {args.length / 1e6:g} Mbp random "
+            "config": {"workload": f"{name}: {args.per_gpu} synthetic {args.length / 1e6:g} Mbp random "
                                    f"genomes per GPU (half in / half out over the {args.per_gpu * world}-genome "
                                    f"family, mu=0.01, planted SNP / 10 kb"
                                    + (", independent genomes" if args.independent else "")
                                    + (", 0.1 % N runs + 5 % lower case" if args.masked else "")
-                                   + f"), {L}/{D}/{R} spacer search",
-                       "kmers_per_step": kmers_total, "candidates": int(ncand),
-                       "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else " + tree-reduce of candidates")},
+                                   + f"), {L}/{Dg}/{R} (k={k})",
+                       "baseline_config": name,
+                       "step": "sort every genome + n-way intersect + filter"
+                               + ("" if args.no_collect else " + collect the candidate records (resident in HBM)"),
+                       "kmers_per_step": kmers_total, "candidates": int(ncand), "records": int(records_total),
+                       "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else
+                                      f" + tree-reduce of candidates ({args.transport})")},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(config, L, D, R, args.cpu_length, args.length)
+            out["cpu_baseline"] = cpu_baseline(config, L, Dg, R, args.cpu_length, args.length, args.per_gpu)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if comm:
+        eng.comm_barrier()
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -123,6 +123,32 @@ int64_t kr_cands_load(kr_ctx*, const kr_cand* cands, size_t n);
  * other == NULL / n == 0 with apply_filter just filters.  Returns the new count. */
 int64_t kr_cands_merge(kr_ctx*, const kr_cand* other, size_t n, int have_other, int apply_filter);
 
+/* ---- multi-GPU: one process (one context) per GPU, genomes sharded over the ranks.  Sort and
+ * local intersect need no communication; the ONE exchange step is a binary-tree reduction of the
+ * candidate lists -- the reference's merge tree (krisp_fasta/intersectAmplicons.py:256-307: pairs of
+ * sorted files merged level by level) with GPUs in place of files -- then a broadcast of the
+ * survivors for the local kr_collect and a gather of the records on rank 0.  RCCL point-to-point on
+ * the context's stream, device buffer to device buffer (xGMI inside a node).  Rendezvous: rank 0
+ * calls kr_comm_unique_id and hands the KR_COMM_ID_BYTES bytes to the other ranks any way it likes
+ * (a file, an environment variable, MPI, torch.distributed); every rank then calls kr_comm_init.
+ * kr_comm_init_dir is the rehearsal transport (the same bytes through files in `dir`) for ranks
+ * that share one GPU, where RCCL refuses duplicate devices: tests on a one-GPU box use it. */
+#define KR_COMM_ID_BYTES 128
+int     kr_comm_unique_id(uint8_t* id);
+int     kr_comm_init(kr_ctx*, int rank, int world, const uint8_t* id);
+int     kr_comm_init_dir(kr_ctx*, int rank, int world, const char* dir);
+int     kr_comm_destroy(kr_ctx*);
+int     kr_comm_rank(kr_ctx*);
+int     kr_comm_world(kr_ctx*);
+int     kr_comm_barrier(kr_ctx*);                               /* syncs the stream, then all ranks meet */
+/* vals[0..n) reduced over all ranks, n <= 8: op 0 = sum, 1 = max; the result on every rank */
+int     kr_comm_allreduce(kr_ctx*, double* vals, int n, int op);
+/* candidates := those present on EVERY rank, masks OR-ed (filtered when apply_filter), on rank 0;
+ * returns the count on rank 0, 0 elsewhere (the other ranks' sets are spent) */
+int64_t kr_cands_reduce(kr_ctx*, int apply_filter);
+int64_t kr_cands_bcast(kr_ctx*);                                /* rank 0's candidates -> every rank */
+int64_t kr_records_gather(kr_ctx*);                             /* every rank's kr_collect records -> rank 0 (kr_fetch) */
+
 /* For every candidate and every listed genome: its distinct keys + multiplicities.
  * Returns #records; fetch them (unordered) with kr_fetch. */
 int64_t kr_collect(kr_ctx*, const int* genome_ids, int n);

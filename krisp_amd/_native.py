@@ -19,6 +19,7 @@ RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
 WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS = 0, 1, 2, 3, 4
 WIDE_MAX_K = 128
+COMM_ID_BYTES = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
 OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE = 1, 2, 3, 4
@@ -55,6 +56,17 @@ SYMBOLS = [
     ("kr_cands_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
     ("kr_cands_load", _c.c_int64, [_P, _P, _c.c_size_t]),
     ("kr_cands_merge", _c.c_int64, [_P, _P, _c.c_size_t, _c.c_int, _c.c_int]),
+    ("kr_comm_unique_id", _c.c_int, [_P]),
+    ("kr_comm_init", _c.c_int, [_P, _c.c_int, _c.c_int, _P]),
+    ("kr_comm_init_dir", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_char_p]),
+    ("kr_comm_destroy", _c.c_int, [_P]),
+    ("kr_comm_rank", _c.c_int, [_P]),
+    ("kr_comm_world", _c.c_int, [_P]),
+    ("kr_comm_barrier", _c.c_int, [_P]),
+    ("kr_comm_allreduce", _c.c_int, [_P, _P, _c.c_int, _c.c_int]),
+    ("kr_cands_reduce", _c.c_int64, [_P, _c.c_int]),
+    ("kr_cands_bcast", _c.c_int64, [_P]),
+    ("kr_records_gather", _c.c_int64, [_P]),
     ("kr_collect", _c.c_int64, [_P, _P, _c.c_int]),
     ("kr_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
     ("kr_set_params_wide", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_size_t]),
@@ -121,6 +133,16 @@ def fasta_to_bases(data, universal_newlines, one_shot=True):
     if n < 0:
         raise KrispHipError(f"kr_fasta_to_bases: [{n}]")
     return out[:n], int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
+
+
+def comm_unique_id():
+    """the RCCL unique id (rank 0 makes it, every rank passes it to Engine.comm_init)"""
+    lib = load()
+    buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+    rc = lib.kr_comm_unique_id(_ptr(buf))
+    if rc < 0:
+        raise KrispHipError(f"kr_comm_unique_id: [{rc}] " + lib.kr_last_error(None).decode())
+    return buf.tobytes()
 
 
 def scan_special_starts(bases, k, omit_soft):
@@ -265,12 +287,44 @@ class Engine:
                                                    len(other), 1, 1 if apply_filter else 0),
                            "kr_cands_merge")
 
-    def collect(self, gids):
+    def collect(self, gids, fetch=True):
         ids = np.asarray(gids, dtype=np.int32)
         n = self._check(self.lib.kr_collect(self.ctx, _ptr(ids), len(ids)), "kr_collect")
+        return self.fetch_records(n) if fetch else n
+
+    def fetch_records(self, n):
         out = np.empty(max(n, 1), dtype=RECORD)
         self._check(self.lib.kr_fetch(self.ctx, _ptr(out), n), "kr_fetch")
         return out[:n]
+
+    # ---- multi-GPU exchange (one process / context per GPU; krisp_amd/distributed.py does the rendezvous)
+    def comm_init(self, rank, world, comm_id):
+        """RCCL communicator from the unique id rank 0 made (comm_unique_id)"""
+        buf = np.frombuffer(comm_id, dtype=np.uint8)
+        assert len(buf) == COMM_ID_BYTES
+        self._check(self.lib.kr_comm_init(self.ctx, rank, world, _ptr(buf)), "kr_comm_init")
+
+    def comm_init_dir(self, rank, world, directory):
+        """rehearsal transport: the same messages through files (ranks may share a GPU)"""
+        self._check(self.lib.kr_comm_init_dir(self.ctx, rank, world, os.fsencode(directory)), "kr_comm_init_dir")
+
+    def comm_barrier(self):
+        self._check(self.lib.kr_comm_barrier(self.ctx), "kr_comm_barrier")
+
+    def comm_allreduce(self, values, op="sum"):
+        v = np.asarray(values, dtype=np.float64).copy()
+        self._check(self.lib.kr_comm_allreduce(self.ctx, _ptr(v), len(v), 1 if op == "max" else 0), "kr_comm_allreduce")
+        return v
+
+    def cands_reduce(self, apply_filter):
+        """tree reduction of every rank's candidates onto rank 0 (the count there, 0 elsewhere)"""
+        return self._check(self.lib.kr_cands_reduce(self.ctx, 1 if apply_filter else 0), "kr_cands_reduce")
+
+    def cands_bcast(self):
+        return self._check(self.lib.kr_cands_bcast(self.ctx), "kr_cands_bcast")
+
+    def records_gather(self):
+        return self._check(self.lib.kr_records_gather(self.ctx), "kr_records_gather")
 
     # ---- wide windows (k > 32 or D > 16)
     def set_params_wide(self, L, D, R, omit_soft=False, max_bases=0):

@@ -1,15 +1,22 @@
-"""Multi-GPU sharding of the krisp_fasta path: one process per GPU, genomes
-sharded across ranks, no collective on the sort/intersect data path, and ONE
-exchange step -- a binary-tree reduction of candidate lists (the reference does
-the same reduction as a tree of pairwise file merges on one host,
-krisp_fasta/intersectAmplicons.py:256-307).
+"""Multi-GPU sharding of the krisp_fasta path: one process per GPU, genomes sharded across
+ranks, no collective on the sort / intersect data path, and ONE exchange step -- a binary-tree
+reduction of candidate lists (the reference does the same reduction as a tree of pairwise file
+merges on one host, krisp_fasta/intersectAmplicons.py:256-307).
 
-`torch.distributed` is plumbing only (rendezvous, barrier, send/recv: backend
-"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  The merge of
-two candidate lists runs on the device (kr_cands_merge) -- `engine` is a
-krisp_amd._native.Engine, or any object with the same cands() / merge_cands()
-/ load_cands() methods (the gloo tests drive this module with a CPU stand-in).
+The exchange itself lives in the library (csrc/h_comm.inc: RCCL send / recv between device
+buffers, device-side list merges): `connect()` below only does the rendezvous -- rank 0 makes
+the RCCL unique id and leaves it in a file the other ranks wait for -- so neither PyTorch nor
+MPI is needed; `torch.distributed.run` (or any launcher that sets RANK / LOCAL_RANK /
+WORLD_SIZE) merely starts the processes.
+
+The functions that take a `dist` argument are the same tree written over torch.distributed
+send / recv with host bounces.  They are not used by the product path any more; the CPU tests
+(tests/test_distributed.py, gloo, a CPU stand-in engine) keep them as the executable statement
+of the tree's semantics: "tree-reduce of per-rank lists == n-way intersection".
 """
+import os
+import time
+
 import numpy as np
 
 from ._native import CAND
@@ -20,6 +27,64 @@ def shard(items, rank, world):
     return [x for i, x in enumerate(items) if i % world == rank]
 
 
+def env_rank_world():
+    """(rank, local_rank, world) as torch.distributed.run / mpirun / srun export them"""
+    e = os.environ
+    rank = int(e.get("RANK", e.get("OMPI_COMM_WORLD_RANK", e.get("SLURM_PROCID", "0"))))
+    world = int(e.get("WORLD_SIZE", e.get("OMPI_COMM_WORLD_SIZE", e.get("SLURM_NTASKS", "1"))))
+    local = int(e.get("LOCAL_RANK", e.get("OMPI_COMM_WORLD_LOCAL_RANK", e.get("SLURM_LOCALID", str(rank)))))
+    return rank, local, world
+
+
+def rendezvous_path(world):
+    """Where rank 0 leaves the RCCL unique id.  KRISP_COMM_FILE names it explicitly; else a name
+    every rank of ONE launch derives alike and no other launch shares: the launcher's pid (the
+    parent of all ranks), the master port and the world size."""
+    p = os.environ.get("KRISP_COMM_FILE")
+    if p:
+        return p
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    return os.path.join(tmp, f"krisp_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{world}")
+
+
+def connect(engine, rank, world, transport="rccl", path=None, timeout_s=600):
+    """Give `engine` its communicator.  transport "rccl": one GPU per rank, the unique id goes
+    through the file `path`; "dir": the rehearsal transport (messages through files in the
+    directory `path`; ranks may share a GPU)."""
+    from . import _native
+    path = path or rendezvous_path(world)
+    if transport == "dir":
+        engine.comm_init_dir(rank, world, path + ".d")
+        return
+    if transport != "rccl":
+        raise ValueError(f"unknown transport {transport!r}")
+    if world == 1:
+        engine.comm_init(0, 1, _native.comm_unique_id())
+        return
+    if rank == 0:
+        cid = _native.comm_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(cid)
+        os.replace(path + ".tmp", path)            # (atomic: a reader never sees a partial id)
+    else:
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s} s")
+            time.sleep(0.005)
+        with open(path, "rb") as f:
+            cid = f.read()
+    engine.comm_init(rank, world, cid)             # (collective: returns once every rank has joined)
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+# ----------------------------------------------------------------------------
+# the same tree over torch.distributed (CPU tests; see the module docstring)
+# ----------------------------------------------------------------------------
 def _to_tensor(arr, device):
     import torch
     t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).reshape(-1).copy())

@@ -374,86 +374,100 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     return finish(groups), stats
 
 
+class PeerFailed(RuntimeError):
+    """another rank of a multi-GPU run raised; this rank stops with it instead of waiting in a collective"""
+
+
 def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,
-                             backend="nccl", verbose=False):
-    """find_regions over several GPUs: launched once per GPU by torch.distributed.run (RANK /
-    LOCAL_RANK / WORLD_SIZE in the environment).  Genomes are sharded round-robin over the ranks
-    (ingroup and outgroup files interleaved so that every rank can prune with the monotone
-    filter), each rank sorts and intersects its own, the candidate lists are tree-reduced
-    (krisp_amd/distributed.py), the survivors broadcast, every rank collects its genomes'
-    records and rank 0 gathers them.  Returns (groups, stats) on rank 0 and (None, stats) elsewhere.
-    The one-key path only (k <= 32, D <= 16), no IUPAC letters: those need look-ups across all
-    genomes and stay on one GPU."""
-    import torch
-    import torch.distributed as dist
+                             transport="rccl", verbose=False):
+    """find_regions over several GPUs: one process per GPU (started by torch.distributed.run,
+    mpirun, srun ...: RANK / LOCAL_RANK / WORLD_SIZE in the environment; no PyTorch involved).
+    Genomes are sharded round-robin over the ranks (ingroup and outgroup files interleaved so that
+    every rank can prune with the monotone filter), each rank sorts and intersects its own, the
+    candidate lists are tree-reduced between the GPUs (kr_cands_reduce: RCCL, device to device),
+    the survivors broadcast, every rank collects its genomes' records and rank 0 gathers them.
+    Returns (groups, stats) on rank 0 and (None, stats) elsewhere.  The one-key path only
+    (k <= 32, D <= 16), no IUPAC letters, no RNA: those need look-ups across all genomes and stay
+    on one GPU.  A rank that fails (missing file, illegal character, out of memory) makes every
+    rank raise before the next collective: nobody is left waiting."""
     from . import _native
     from . import distributed as D
     k = amplicon_len
     Le, De, Re = codec.effective_geometry(L, k - L - R, R)
     _check_geometry(Le, De, Re)
     do_filter = k > L + R
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = None
-    if backend == "gloo":                 # rehearsal: ranks share the visible GPU(s)
-        local_rank %= max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="gloo")
-    else:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        device = torch.device("cuda", local_rank)
-    try:
-        # interleave ingroup / outgroup files so that a round-robin shard holds both kinds
-        ing, outg = list(ingroup_files), list(outgroup_files)
-        order = []
-        for i in range(max(len(ing), len(outg))):
-            if i < len(ing):
-                order.append((ing[i], True))
-            if i < len(outg):
-                order.append((outg[i], False))
-        if len(order) < world:
-            raise ValueError(f"{len(order)} genomes cannot be sharded over {world} GPUs")
-        mine = D.shard(list(range(len(order))), rank, world)
+    rank, local_rank, world = D.env_rank_world()
+    # interleave ingroup / outgroup files so that a round-robin shard holds both kinds
+    ing, outg = list(ingroup_files), list(outgroup_files)
+    order = []
+    for i in range(max(len(ing), len(outg))):
+        if i < len(ing):
+            order.append(ing[i])
+        if i < len(outg):
+            order.append(outg[i])
+    if len(order) < world:
+        raise ValueError(f"{len(order)} genomes cannot be sharded over {world} GPUs")
+    labels = [simplename(f) for f in order]
+    # ingroup / outgroup by LABEL, as the reference classifies (Amplicon.py:495-521) and as
+    # find_regions does: an outgroup file whose label equals an ingroup label counts as ingroup
+    ingroup_labels = frozenset(simplename(f) for f in ing)
+    mine = D.shard(list(range(len(order))), rank, world)
+    if transport == "dir":                 # rehearsal: the ranks share the visible GPU(s)
+        local_rank %= max(1, int(os.environ.get("KRISP_VISIBLE_GPUS", "1")))
+
+    with _native.Engine(device=local_rank) as eng:
+        D.connect(eng, rank, world, transport=transport)
+
+        def together(fn):
+            """run fn() on this rank; every rank learns whether all succeeded before anyone goes on"""
+            err, out = None, None
+            try:
+                out = fn()
+            except BaseException as e:  # noqa: BLE001
+                err = e
+            failed = eng.comm_allreduce([1.0 if err is not None else 0.0], "max")[0] > 0
+            if err is not None:
+                raise err
+            if failed:
+                raise PeerFailed(f"rank {rank}: another rank failed")
+            return out
+
         t0 = time.time()
-        loaded = [fasta.ingest(order[g][0], k, omit_soft) for g in mine]
-        bad = torch.tensor([1 if any(sp for _, _, sp in loaded) else 0, 1 if any(r for _, r, _ in loaded) else 0])
-        bad = bad.to(device) if device is not None else bad
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad[0]):
+        loaded = together(lambda: [fasta.ingest(order[g], k, omit_soft) for g in mine])
+        kinds = eng.comm_allreduce([1.0 if any(sp for _, _, sp in loaded) else 0.0,
+                                    1.0 if any(r for _, r, _ in loaded) else 0.0,
+                                    float(max(len(b) for b, _, _ in loaded))], "max")
+        if kinds[0]:
             raise fasta.IupacWindowsUnsupported("IUPAC ambiguity letters: run on one GPU (their groups need "
                                                 "look-ups across all genomes)")
-        if int(bad[1]):
+        if kinds[1]:
             raise MixedAlphabet("RNA input: run on one GPU")
-        labels = [simplename(f) for f, _ in order]
         stats = {"read_s": time.time() - t0}
         t1 = time.time()
-        maxlen = torch.tensor([max(len(b) for b, _, _ in loaded)], dtype=torch.int64)
-        maxlen = maxlen.to(device) if device is not None else maxlen
-        dist.all_reduce(maxlen, op=dist.ReduceOp.MAX)
         quirk_all_fail = do_filter and De == 0
-        with _native.Engine(device=local_rank) as eng:
-            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=int(maxlen.item()))
+        filt = do_filter and not quirk_all_fail
+
+        def device_part():
+            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=int(kinds[2]))
             for g, (bases, _, _) in zip(mine, loaded):
                 eng.upload(g, bases)
                 eng.sort(g)
-            flags = [order[g][1] for g in mine]
-            eng.intersect(mine, flags, apply_filter=do_filter and not quirk_all_fail)    # safe local pruning
-            ncand = D.tree_reduce_candidates(eng, dist, rank, world, apply_filter=do_filter and not quirk_all_fail,
-                                             device=device)
-            D.broadcast_candidates(eng, dist, rank, world, device=device)
-            counts = sum(eng.count(g) for g in mine)
-            recs = eng.collect(mine) if not quirk_all_fail else np.empty(0, dtype=_native.RECORD)
-            allrec = D.gather_records(recs, dist, rank, world, device=device)
-        stats.update(device_s=time.time() - t1, kmers=int(counts), candidates=int(max(ncand, 0)))
-        if rank != 0:
-            return None, stats
-        if quirk_all_fail:
-            return [], stats
-        return amplicon.groups_from_records(allrec, labels, Le, De, Re), stats
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+            eng.intersect(mine, [labels[g] in ingroup_labels for g in mine], apply_filter=filt)    # safe local pruning
+            return sum(eng.count(g) for g in mine)
+
+        counts = together(device_part)
+        ncand = eng.cands_reduce(apply_filter=filt)
+        eng.cands_bcast()
+        nrec = together(lambda: 0 if quirk_all_fail else eng.collect(mine, fetch=False))
+        total = eng.records_gather() if not quirk_all_fail else 0
+        allrec = eng.fetch_records(total) if rank == 0 and not quirk_all_fail else None
+        eng.comm_barrier()
+        stats.update(device_s=time.time() - t1, kmers=int(counts), candidates=int(max(ncand, 0)), records=int(nrec))
+    if rank != 0:
+        return None, stats
+    if quirk_all_fail:
+        return [], stats
+    return amplicon.groups_from_records(allrec, labels, Le, De, Re), stats
 
 
 # ----------------------------------------------------------------------------
@@ -738,7 +752,7 @@ def main(argv=None):
         # one process per GPU (python -m torch.distributed.run ... -m krisp_amd.krisp_fasta ...)
         groups, stats = find_regions_distributed(args.files, args.outgroup, args.conserved_left,
                                                  args.conserved_right, args.amplicon, omit_soft=args.omit_soft,
-                                                 backend=os.environ.get("KRISP_DIST_BACKEND", "nccl"),
+                                                 transport=os.environ.get("KRISP_COMM_TRANSPORT", "rccl"),
                                                  verbose=args.verbose)
         if groups is None:
             return 0                     # rank 0 writes the output

@@ -255,25 +255,28 @@ DIST_WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ["KR_ROOT"])
-import torch.distributed as dist
 from krisp_amd import _native, distributed as D, synth
 from oracle import kmer_oracle as K
 
 L, Dg, R = 25, 1, 2
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
+rank, _, world = D.env_rank_world()
 fam = synth.family(6, 3, 3, 150_000, records=3, mu=0.01, snp_every=1500)
 mine = D.shard(list(range(len(fam))), rank, world)
 eng = _native.Engine(device=0)
+D.connect(eng, rank, world, transport="dir", path=os.environ["KR_COMM"])
 eng.set_params(L, Dg, R, max_bases=max(len(t) for _, _, t in fam))
 for g in mine:
     eng.upload(g, fam[g][2])
     eng.sort(g)
 eng.intersect(mine, [fam[g][1] for g in mine], apply_filter=False)
-n = D.tree_reduce_candidates(eng, dist, rank, world, apply_filter=True)
-D.broadcast_candidates(eng, dist, rank, world)
-recs = eng.collect(mine)
-allrec = D.gather_records(recs, dist, rank, world)
+s = eng.comm_allreduce([float(rank + 1), 1.0], "sum")
+assert s[0] == world * (world + 1) / 2 and s[1] == world
+assert eng.comm_allreduce([float(rank)], "max")[0] == world - 1
+n = eng.cands_reduce(apply_filter=True)
+nb = eng.cands_bcast()
+assert nb == eng.comm_allreduce([float(n)], "max")[0]
+nloc = eng.collect(mine, fetch=False)
+total = eng.records_gather()
 if rank == 0:
     keys = [K.sorted_keys(t.tobytes(), L, Dg, R) for _, _, t in fam]
     want = K.intersect(keys, [f for _, f, _ in fam], L, Dg, R, apply_filter=True)
@@ -281,37 +284,75 @@ if rank == 0:
     assert n == len(want) > 0, (n, len(want))
     assert np.array_equal(got["prefix"], want["prefix"]) and np.array_equal(got["in_mask"], want["in_mask"])
     assert np.array_equal(got["out_mask"], want["out_mask"])
-    a = np.sort(allrec, order=["key", "genome"])
+    a = np.sort(eng.fetch_records(total), order=["key", "genome"])
     b = np.sort(K.collect(keys, want, L, Dg, R), order=["key", "genome"])
     assert np.array_equal(a, b)
-    print("GPU_DIST_OK", n, len(allrec))
-dist.barrier()
+    print("GPU_DIST_OK", n, total)
+eng.comm_barrier()
 eng.close()
-dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
-    """The real engine in the N > 1 flow (sharding, device list merges, broadcast, gather);
-    two processes on cuda:0, gloo transport (RCCL needs one GPU per rank)."""
-    import socket
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_ranks_sharing_the_gpu_run_the_library_exchange(world, tmp_path):
+    """The exchange step of the N > 1 flow as the library does it (csrc/h_comm.inc): sharding, tree
+    reduction with device-side list merges, broadcast, local collect, gather -- `world` processes
+    on cuda:0 with the file transport (RCCL wants one GPU per rank), against the packed oracle's
+    n-way intersection.  world = 3, 5: ranks without a partner in some rounds."""
     import subprocess
     import sys
     script = tmp_path / "w.py"
     script.write_text(DIST_WORKER)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KR_ROOT=ROOT)
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), KR_ROOT=ROOT,
+                   KR_COMM=str(tmp_path / "comm"))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "GPU_DIST_OK" in outs[0], outs[0]
+
+
+def test_rccl_communicator_at_world_size_one():
+    """RCCL itself on this box: unique id, ncclCommInitRank, all-reduce, barrier, and the exchange
+    calls (no partner: they return at once) -- what a one-GPU box can exercise of the RCCL transport"""
+    from krisp_amd import _native, synth
+    fam = synth.family(8, 1, 1, 60_000, records=2, mu=0.01, snp_every=1000)
+    with _native.Engine(device=0) as eng:
+        eng.comm_init(0, 1, _native.comm_unique_id())
+        eng.set_params(25, 1, 2, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            eng.add(i, t)
+        n0 = eng.intersect([0, 1], [True, False], apply_filter=True)
+        assert eng.comm_allreduce([3.0, 4.0], "sum").tolist() == [3.0, 4.0]
+        eng.comm_barrier()
+        assert eng.cands_reduce(apply_filter=True) == n0
+        assert eng.cands_bcast() == n0
+        nrec = eng.collect([0, 1], fetch=False)
+        assert eng.records_gather() == nrec
+
+
+def test_a_failing_rank_stops_every_rank(tmp_path):
+    """krisp_fasta over several ranks when ONE rank cannot read its genome: every rank exits with an
+    error promptly (the failing rank with its own exception, the others with PeerFailed) instead of
+    waiting in a collective"""
+    import subprocess
+    import sys
+    case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
+    paths = _paths(case, tmp_path)
+    files = [paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
+    files[1] = str(tmp_path / "does_not_exist.fasta")          # genome 2 of the interleaved order -> rank 0 or 1
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), KRISP_COMM_TRANSPORT="dir",
+                   KRISP_COMM_FILE=str(tmp_path / "comm"))
+        procs.append(subprocess.Popen([sys.executable, "-m", "krisp_amd.krisp_fasta"] + files + case["main_args"],
+                                      cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode != 0 for p in procs), outs
+    assert any("FileNotFoundError" in o or "No such file" in o for o in outs), outs
+    assert any("PeerFailed" in o for o in outs), outs
 
 
 def test_iupac_kmers_join_the_device_results(tmp_path):
@@ -471,8 +512,8 @@ def test_kstream_command_line_as_documented(tmp_path):
 @pytest.mark.parametrize("world", [2, 3])
 def test_krisp_fasta_command_line_over_several_ranks(world, tmp_path):
     """python -m torch.distributed.run ... -m krisp_amd.krisp_fasta: genomes sharded over the ranks
-    (here sharing the one GPU, lists over gloo), candidate tree reduction, records gathered to rank 0
-    -- the output is the reference's, byte for byte"""
+    (here sharing the one GPU: the file transport of the library's exchange), candidate tree reduction,
+    records gathered to rank 0 -- the output is the reference's, byte for byte"""
     import subprocess
     import sys
     case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
@@ -483,7 +524,7 @@ def test_krisp_fasta_command_line_over_several_ranks(world, tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + world), "-m", "krisp_amd.krisp_fasta"]
     cmd += [paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
     cmd += case["main_args"] + ["--out_align", aln, "--out_csv", csvp]
-    env = dict(os.environ, KRISP_DIST_BACKEND="gloo")
+    env = dict(os.environ, KRISP_COMM_TRANSPORT="dir", KRISP_COMM_FILE=str(tmp_path / "comm"))
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert open(csvp).read() == case["csv"]
