@@ -150,7 +150,7 @@ int64_t kr_cands_bcast(kr_ctx*);                                /* rank 0's cand
 int64_t kr_records_gather(kr_ctx*);                             /* every rank's kr_collect records -> rank 0 (kr_fetch) */
 
 /* For every candidate and every listed genome: its distinct keys + multiplicities.
- * Returns #records; fetch them (unordered) with kr_fetch. */
+ * Returns #records; kr_fetch returns them ordered by (key, position of the genome in genome_ids). */
 int64_t kr_collect(kr_ctx*, const int* genome_ids, int n);
 int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
 

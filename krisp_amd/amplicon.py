@@ -87,10 +87,18 @@ def groups_from_records(records, labels, L, D, R, rna=False):
     by_name = np.argsort(np.array(labels, dtype=object), kind="stable")
     label_rank = np.empty(len(labels), dtype=np.int64)
     label_rank[by_name] = np.arange(len(labels))
-    order = np.lexsort((label_rank[records["genome"].astype(np.int64)], records["key"]))
-    keys = records["key"][order]
-    genome = records["genome"][order]
-    count = records["count"][order]
+    rk = label_rank[records["genome"].astype(np.int64)]
+    kk = records["key"]
+    # kr_collect returns (key, position of the genome in the call) order: callers that list the
+    # genomes by label get records that need no sort (one vectorised check instead of a lexsort)
+    in_order = len(kk) < 2 or bool(np.all((kk[1:] > kk[:-1]) | ((kk[1:] == kk[:-1]) & (rk[1:] >= rk[:-1]))))
+    if in_order:
+        keys, genome, count = kk, records["genome"], records["count"]
+    else:
+        order = np.lexsort((rk, kk))
+        keys = kk[order]
+        genome = records["genome"][order]
+        count = records["count"][order]
     pm = codec.prefix_mask(L, R)
     new_key = np.ones(len(keys), dtype=bool)
     new_key[1:] = keys[1:] != keys[:-1]

@@ -359,7 +359,9 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
         if verbose:
             for f, c in zip(files, counts):
                 print(f"=> Extracted and sorted {c:,} {k}-kmers from {f}", file=sys.stderr)
-        records = eng.collect(ids) if (ncand and not quirk_all_fail) else np.empty(0, dtype=_native.RECORD)
+        # (genomes listed by label: kr_collect's (key, position in the call) order is then the renderer's)
+        by_label = sorted(ids, key=lambda i: labels[i])
+        records = eng.collect(by_label) if (ncand and not quirk_all_fail) else np.empty(0, dtype=_native.RECORD)
         touched, sgroups = set(), []
         if any(specials) and not quirk_all_fail:
             touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels,
@@ -561,7 +563,8 @@ def mergeFiles(files, output, parallel=1, workdir=None, verbose=True, device=0):
             eng.load_sorted(i, keys)
         ids = list(range(len(files)))
         ncand = eng.intersect(ids, [True] * len(ids), apply_filter=False)
-        records = eng.collect(ids) if ncand else np.empty(0, dtype=_native.RECORD)
+        by_label = sorted(ids, key=lambda i: labels[i])
+        records = eng.collect(by_label) if ncand else np.empty(0, dtype=_native.RECORD)
         touched, sgroups = set(), []
         if any(specials):
             touched, sgroups = _special_groups(eng, ids, labels, specials, (L, D, R), frozenset(), False)

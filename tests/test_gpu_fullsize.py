@@ -3,9 +3,11 @@ sizes in seconds): record count = 2 x valid windows, sortedness (adjacent invers
 counted on the device), idempotence of sort + intersect, every candidate re-found by the
 collect in every genome, agreement between slicing configurations.
 
-  * BASELINE configs[1] (4 x 50 Mbp, 25/1/2) runs in the regular `-m gpu` suite.
-  * BASELINE configs[4] (2 x 3 Gbp, k = 31 as 28/1/2; 16 key-space slices, ~100 GB of HBM)
-    is opt-in: KR_RUN_C5=1 (minutes of host-side genome generation).
+  * BASELINE configs[1] (4 x 50 Mbp, 25/1/2), configs[2] (8 x 500 Mbp, 32/60/32: the wide path) and
+    configs[4] (2 x 3 Gbp, k = 31 as 28/1/2; 64 key-space slices, ~150 GB of HBM) all run in the
+    regular `-m gpu` suite (KR_SKIP_BIG=1 leaves the two large ones out: ~2 minutes of host-side
+    genome generation each).  configs[3] (32 genomes on 8 GPUs) needs the 8-GPU node; its
+    per-GPU load and its whole genome set on one GPU are bench.py variants (profiles/).
 """
 import os
 
@@ -27,20 +29,35 @@ def _valid_windows(text, k):
     return int(np.maximum(lens - k + 1, 0).sum())
 
 
-def _run(fam, L, D, R, slice_bases=None):
+def _check_records(recs, c1, flags, ids, L, D, R):
+    """every candidate is present in every genome, and ingroup / outgroup diagnostic bases differ"""
+    n1 = len(c1)
+    pm = np.uint64((~0 << (64 - 2 * (L + R))) & 0xFFFFFFFFFFFFFFFF)
+    pre = recs["key"] & pm
+    for i in ids:
+        assert np.array_equal(np.unique(pre[recs["genome"] == i]), c1["prefix"])
+    if D == 1:
+        dshift = np.uint64(62 - 2 * (L + R))
+        base = ((recs["key"] >> dshift) & np.uint64(3)).astype(np.int64)
+        is_in = np.array(flags)[recs["genome"]]
+        idx = np.searchsorted(c1["prefix"], pre)
+        in_sets = np.zeros(n1, dtype=np.int64)
+        out_sets = np.zeros(n1, dtype=np.int64)
+        np.bitwise_or.at(in_sets, idx[is_in], 1 << base[is_in])
+        np.bitwise_or.at(out_sets, idx[~is_in], 1 << base[~is_in])
+        assert np.all((in_sets & out_sets) == 0)
+        assert np.array_equal(in_sets, c1["in_mask"].astype(np.int64))
+        assert np.array_equal(out_sets, c1["out_mask"].astype(np.int64))
+
+
+def _run(fam, L, D, R, slice_bases=None, light=False):
+    """light: for results too large for host-side set arithmetic (configs[4]: 6.5e7 candidates) --
+    no second sort, and the record checks on a seeded sample of 20000 candidates"""
     from krisp_amd import _native
-    old = os.environ.get("KR_SLICE_BASES")
+    eng = _native.Engine()
     if slice_bases is not None:
-        os.environ["KR_SLICE_BASES"] = str(slice_bases)
-    try:
-        eng = _native.Engine()
-        eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
-    finally:
-        if slice_bases is not None:
-            if old is None:
-                del os.environ["KR_SLICE_BASES"]
-            else:
-                os.environ["KR_SLICE_BASES"] = old
+        eng.set_option(_native.OPT_SLICE_BASES, slice_bases)
+    eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
     ids = list(range(len(fam)))
     flags = [f for _, f, _ in fam]
     for i, (_, _, t) in enumerate(fam):
@@ -52,32 +69,21 @@ def _run(fam, L, D, R, slice_bases=None):
     for i, (_, _, t) in enumerate(fam):
         assert eng.count(i) == 2 * _valid_windows(t, L + D + R)
         assert eng.inversions(i) == 0
-    # idempotence: sorting again from the resident bases and intersecting again changes nothing
-    for i in ids:
-        eng.sort(i)
-    assert eng.intersect(ids, flags, apply_filter=True) == n1
-    c2 = eng.cands()
-    assert np.array_equal(c1, c2)
     assert np.all(np.diff(c1["prefix"].astype(np.uint64)) > 0) if n1 > 1 else True
-    # every candidate is present in every genome, and ingroup / outgroup diagnostic bases differ
-    recs = eng.collect(ids)
-    pm = np.uint64((~0 << (64 - 2 * (L + R))) & 0xFFFFFFFFFFFFFFFF)
-    pre = recs["key"] & pm
-    for i in ids:
-        assert np.array_equal(np.unique(pre[recs["genome"] == i]), c1["prefix"])
-    if D == 1:
-        dshift = np.uint64(62 - 2 * (L + R))
-        base = ((recs["key"] >> dshift) & np.uint64(3)).astype(np.int64)
-        is_in = np.array(flags)[recs["genome"]]
-        order = np.argsort(pre, kind="stable")
-        idx = np.searchsorted(c1["prefix"], pre)
-        in_sets = np.zeros(n1, dtype=np.int64)
-        out_sets = np.zeros(n1, dtype=np.int64)
-        np.bitwise_or.at(in_sets, idx[is_in], 1 << base[is_in])
-        np.bitwise_or.at(out_sets, idx[~is_in], 1 << base[~is_in])
-        assert np.all((in_sets & out_sets) == 0)
-        assert np.array_equal(in_sets, c1["in_mask"].astype(np.int64))
-        assert np.array_equal(out_sets, c1["out_mask"].astype(np.int64))
+    if light:
+        rng = np.random.default_rng(99)
+        pick = np.sort(rng.choice(n1, size=min(n1, 20000), replace=False))
+        sample = c1[pick].copy()
+        eng.load_cands(sample)
+        _check_records(eng.collect(ids), sample, flags, ids, L, D, R)
+    else:
+        # idempotence: sorting again from the resident bases and intersecting again changes nothing
+        for i in ids:
+            eng.sort(i)
+        assert eng.intersect(ids, flags, apply_filter=True) == n1
+        c2 = eng.cands()
+        assert np.array_equal(c1, c2)
+        _check_records(eng.collect(ids), c1, flags, ids, L, D, R)
     info = eng.debug_info()
     eng.close()
     return c1, info
@@ -94,12 +100,61 @@ def test_c2_full_size_properties():
     assert np.array_equal(c1, c4)
 
 
-@pytest.mark.skipif(os.environ.get("KR_RUN_C5") != "1", reason="opt-in: KR_RUN_C5=1 (2 x 3 Gbp, ~100 GB HBM)")
+BIG = pytest.mark.skipif(os.environ.get("KR_SKIP_BIG") == "1", reason="KR_SKIP_BIG=1")
+
+
+@BIG
 def test_c5_three_gbp_genomes():
+    """BASELINE configs[4]: 2 x 3 Gbp (1 in / 1 out), k = 31 as 28/1/2: 1.2e10 k-mer records in 64
+    key-space slices (pass 0 over all keys, then pass 1 / pass 2 / LDS sort per slice)"""
+    import time
+    t0 = time.time()
     fam = _family(5, 1, 1, 3_000_000_000)
-    c1, info = _run(fam, 28, 1, 2)
+    t1 = time.time()
+    c1, info = _run(fam, 28, 1, 2, light=True)
     assert info["nslices"] == 64        # 6e9 keys per genome -> slices of <= 1.05e8 keys
-    print("C5:", len(c1), "candidates;", info)
+    assert len(c1) > 10_000_000
+    print(f"\nC5: {len(c1)} candidates; generation {t1 - t0:.0f} s, device + checks {time.time() - t1:.0f} s; {info}")
+
+
+@BIG
+def test_c3_eight_half_gbp_genomes_long_amplicons():
+    """BASELINE configs[2]: 8 x 500 Mbp (4 in / 4 out), 32/60/32 amplicon search -- the wide path with
+    key-space slices; checked through properties (every group holds every genome, groups ascend,
+    one flank pair per group, a diagnostic column separates the groups)"""
+    import time
+    from krisp_amd import _native, amplicon, synth
+    from krisp_amd import krisp_fasta as KF
+    L, D, R = 32, 60, 32
+    t0 = time.time()
+    fam = synth.family(3, 4, 4, 500_000_000, records=24, mu=0.001, snp_every=20000)
+    t1 = time.time()
+    ids = list(range(len(fam)))
+    flags = [f for _, f, _ in fam]
+    with _native.Engine() as eng:
+        eng.set_params_wide(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            eng.upload(i, t)
+        assert eng.debug_info()["nslices"] >= 4
+        t2 = time.time()
+        n = eng.wide_run(ids, flags, apply_filter=True)
+        eng.sync()
+        t3 = time.time()
+        hits = eng.wide_fetch(_native.WIDE_HITS)
+        sizes = [len(eng.wide_fetch(w)) for w in (0, 1, 2)]
+    assert n == len(hits) > 0
+    groups = KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R)
+    names = {nm for nm, _, _ in fam}
+    ingroup = {nm for nm, f, _ in fam if f}
+    pairs = []
+    for g in groups:
+        assert {lab for a in g for lab in a.labels} == names
+        assert len({(a.left, a.right) for a in g}) == 1 and all(len(a.diag) == D for a in g)
+        assert amplicon.ingroup_unique_columns(g, ingroup)
+        pairs.append((g[0].left, g[0].right))
+    assert pairs == sorted(pairs) and len(set(pairs)) == len(pairs) and len(groups) > 100_000
+    print(f"\nC3: {len(groups)} groups, dictL {sizes[0]} dictR {sizes[1]} groups before the filter {sizes[2]}; "
+          f"generation {t1 - t0:.0f} s, upload {t2 - t1:.0f} s, first wide run (with allocations) {t3 - t2:.1f} s")
 
 
 def _groups_packed(fam, L, D, R, do_filter):
@@ -140,7 +195,7 @@ def test_wide_path_equals_the_packed_path_where_both_apply(geo, length, filt, sb
     from krisp_amd import amplicon, synth
     fam = synth.family(11, 2, 2, length, records=7, mu=0.004, snp_every=3000, n_frac=0.001, lower_frac=0.01)
     if sb is not None:
-        monkeypatch.setenv("KR_SLICE_BASES", str(sb))       # both paths sort in 4^sb key-space slices
+        monkeypatch.setenv("KR_SLICE_BASES", str(sb))       # both paths sort in 4^sb key-space slices (environment default of KR_OPT_SLICE_BASES)
         monkeypatch.setenv("KR_WIDE_CACHE", "0")            # and the locate pass re-generates its keys
     a = _groups_packed(fam, *geo, filt)
     b, info = _groups_wide(fam, *geo, filt)

@@ -249,6 +249,13 @@ def test_intersect_and_collect(N, K, L, D, R, length, n):
             got_sorted = np.sort(recs, order=["key", "genome"])
             want_sorted = np.sort(wrec, order=["key", "genome"])
             assert np.array_equal(got_sorted, want_sorted)
+            assert np.array_equal(recs, got_sorted), "kr_collect returns (key, genome position) order"
+            # ... for any order of the genomes in the call: position in the call breaks the ties
+            perm = list(range(n))[::-1]
+            recs2 = e.collect(perm)
+            pos = np.array([perm.index(g) for g in range(n)])
+            o2 = np.lexsort((pos[recs2["genome"].astype(np.int64)], recs2["key"]))
+            assert np.array_equal(o2, np.arange(len(recs2))) and np.array_equal(np.sort(recs2, order=["key", "genome"]), want_sorted)
         # deferred filter == fused filter; list (x) list merge == n-way intersect
         want_f = K.intersect(want_keys, flags, L, D, R, apply_filter=True)
         e.intersect(list(range(n)), flags, apply_filter=False)
