@@ -190,6 +190,16 @@ int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* retu
 int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines, int one_shot, uint8_t* out,
                           size_t cap, int64_t* stats);
 
+/* Host-side ingest of one FILE: read -> inflate (.gz: libdeflate when the box
+ * has it, else zlib; every member of a multi-member file) -> kr_fasta_to_bases, with the reference
+ * reader's semantics for files (kstream.py:458-479: .gz by extension; 510-583).  *bases = a buffer
+ * the library owns -- pinned host memory when a GPU is present, so that kr_genome_upload copies
+ * from it by DMA -- until kr_host_free.  stats[8] = records, characters outside ACGTNacgtn, is_rna,
+ * is_fasta, read us, inflate us, parse us, gzip members | used_libdeflate << 32.  Returns the
+ * number of bytes; .bz2 files return KR_ERR_HOST (the host layer inflates them). */
+int64_t kr_ingest_file(const char* path, uint8_t** bases, int64_t* stats);
+void    kr_host_free(void* p);
+
 /* Host-side (no GPU involved): the side channel of SURVEY 8(b) -- the windows the device's 2-bit
  * alphabet cannot carry.  `bases` is an upload buffer (kr_fasta_to_bases).  Returns the number of
  * window starts (ascending) of windows of k characters that survive the soft-mask rule, hold no

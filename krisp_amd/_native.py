@@ -73,6 +73,8 @@ SYMBOLS = [
     ("kr_wide_run", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_wide_fetch", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_fasta_to_bases", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
+    ("kr_ingest_file", _c.c_int64, [_c.c_char_p, _P, _P]),
+    ("kr_host_free", None, [_P]),
     ("kr_scan_special", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     ("kr_set_option", _c.c_int, [_P, _c.c_int, _c.c_int64]),
     ("kr_sync", _c.c_int, [_P]),
@@ -133,6 +135,45 @@ def fasta_to_bases(data, universal_newlines, one_shot=True):
     if n < 0:
         raise KrispHipError(f"kr_fasta_to_bases: [{n}]")
     return out[:n], int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
+
+
+class _HostBlock:
+    """a buffer the library owns (kr_ingest_file: pinned host memory on a GPU box); freed with the last view"""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.kr_host_free(self.ptr)
+                self.ptr = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def ingest_file(path):
+    """file -> (uint8 upload buffer in library-owned, pinned memory; records; special chars; rna; fasta;
+    timings dict) through kr_ingest_file: read + inflate + parse inside the library, GIL released.
+    Returns None for files the library leaves to the host layer (.bz2)."""
+    lib = load()
+    out = ctypes.c_void_p(0)
+    stats = np.zeros(8, dtype=np.int64)
+    n = lib.kr_ingest_file(os.fsencode(path), ctypes.byref(out), _ptr(stats))
+    if n == ERR_HOST:
+        return None
+    if n < 0:
+        msg = lib.kr_last_error(None).decode()
+        if "cannot open" in msg:
+            raise FileNotFoundError(msg)
+        raise KrispHipError(f"kr_ingest_file({path}): [{n}] {msg}")
+    block = _HostBlock(lib, out.value)
+    raw = (ctypes.c_uint8 * max(int(n), 1)).from_address(out.value)
+    raw._owner = block                       # the view keeps the block alive
+    arr = np.frombuffer(raw, dtype=np.uint8)[:n]
+    timings = dict(read_s=stats[4] / 1e6, inflate_s=stats[5] / 1e6, parse_s=stats[6] / 1e6,
+                   members=int(stats[7] & 0xFFFFFFFF), libdeflate=bool(stats[7] >> 32))
+    return arr, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3]), timings
 
 
 def comm_unique_id():

@@ -24,7 +24,7 @@ def build(force=False, verbose=False):
             and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           f"-I{INC}", "-o", LIB, SRC, "-lrccl"]
+           f"-I{INC}", "-o", LIB, SRC, "-lrccl", "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -7,7 +7,9 @@
 // Integer / byte work, HBM-bound: no MFMA anywhere (DESIGN.md "kernels").
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>       // the one exchange step of the multi-GPU flow (h_comm.inc)
+#include <dlfcn.h>
 #include <sys/stat.h>
+#include <zlib.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -16,7 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cerrno>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -34,6 +38,7 @@
 #include "h_core.inc"        // context, buffers, parameters, upload, sort, finalize   (opens extern "C")
 #include "h_intersect.inc"   // kr_intersect, candidate lists, kr_collect
 #include "h_wide.inc"        // kr_wide_run
+#include "h_ingest.inc"      // file -> inflate -> parse -> pinned upload buffer (host side)
 #include "h_comm.inc"        // multi-GPU exchange: RCCL (or files, for rehearsal) tree reduction of candidates, gather of records
 #include "h_misc.inc"        // timers, debug entries, FASTA text parser
 

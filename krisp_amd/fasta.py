@@ -26,6 +26,10 @@ for _ch in b"ACGTNacgtn\n":
     _PLAIN[_ch] = True
 
 
+# per file: the stage times of the last kr_ingest_file (read / inflate / parse), for the stage tables
+LAST_TIMINGS = {}
+
+
 def _read_raw_lines(filename):
     ext = os.path.splitext(filename)[1]
     if ext in (".gz", ".bz2"):
@@ -70,6 +74,13 @@ def load_bases(filename):
     to_bases(read_records(filename)) through the library's one-pass host parser."""
     from . import _native
     ext = os.path.splitext(filename)[1]
+    if ext != ".bz2":
+        # read + inflate + parse inside the library (kr_ingest_file), into pinned memory
+        got = _native.ingest_file(filename)
+        if got is not None:
+            bases, _nrec, nspecial, rna, _fasta, timings = got
+            LAST_TIMINGS[os.fspath(filename)] = timings
+            return bases, bool(rna), nspecial
     if ext == ".gz":
         with gzip.open(filename, "rb") as f:
             data, universal = f.read(), False
