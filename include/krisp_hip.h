@@ -156,15 +156,17 @@ int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
 
 /* ---- wide windows: amplicons longer than one 64-bit key (L+D+R > 32, or D > 16) ------------
  * The reference has no length limit (its k-mers are text: krisp_fasta.py:21-43 passes any
- * kmers= / split= to kstream, README.md:201-232 runs --conserved 30 --amplicon 100).  Here `left` and `right`
- * still fit one key each (1 <= L, R <= 32) and L+D+R <= KR_WIDE_MAX_K.  The library sorts and
- * intersects three times with the 64-bit pipeline (the `left` spectrum, the `right` spectrum,
- * then exact composite keys rank(left):rank(right)), applies the diagnostic filter
+ * kmers= / split= to kstream, README.md:201-232 runs --conserved 30 --amplicon 100).  Here 1 <= L, R <=
+ * KR_WIDE_MAX_FLANK and L+D+R <= KR_WIDE_MAX_K.  The library sorts and intersects with the 64-bit
+ * pipeline the `left` spectrum, the `right` spectrum, then exact composite keys
+ * rank(left):rank(right) (a flank longer than 32 bases is itself ranked through two spectra and
+ * their combinations: three more sorts), applies the diagnostic filter
  * (Amplicon.py:495-521) and returns, for every surviving (left,right) group, where its member
  * windows lie; the host cuts the text of those windows out of the genomes it already holds.
  * Replaces, for such geometries, the same calls as kr_genome_sort + kr_intersect + kr_collect:
  * extractSortedKmers + mergeFiles + filterAlignments (krisp_fasta.py:237-272). */
-#define KR_WIDE_MAX_K 128
+#define KR_WIDE_MAX_K 256
+#define KR_WIDE_MAX_FLANK 64
 /* one member window of a surviving group: cand = rank of the group in (left,right) order,
  * genome = index into the genome_ids of kr_wide_run, pos = base offset of the window in the
  * uploaded text, strand = 1 when the member is the reverse complement of that window */
@@ -172,8 +174,8 @@ typedef struct { uint32_t cand, genome, pos, strand; } kr_wide_hit;
 int     kr_set_params_wide(kr_ctx*, int L, int D, int R, int softmask_mode, size_t max_bases);
 /* genomes: kr_genome_upload.  Returns the number of hits (grouped by cand, ascending). */
 int64_t kr_wide_run(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup, int apply_filter);
-enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted */
-       KR_WIDE_DICT_RIGHT = 1,  /* u64: rights present in all genomes, sorted */
+enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L > 32: their rank:rank combinations) */
+       KR_WIDE_DICT_RIGHT = 1,  /* u64: rights present in all genomes, sorted (R > 32: likewise) */
        KR_WIDE_GROUPS = 2,      /* u64: composite keys of the groups present in all genomes (before the filter) */
        KR_WIDE_HITS = 3,        /* kr_wide_hit */
        KR_WIDE_COUNTS = 4 };    /* u64 per genome of the last run: its k-mer records (2 x valid windows) */

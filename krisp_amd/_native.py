@@ -18,7 +18,8 @@ CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
 WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS = 0, 1, 2, 3, 4
-WIDE_MAX_K = 128
+WIDE_MAX_K = 256
+WIDE_MAX_FLANK = 64
 COMM_ID_BYTES = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
@@ -29,7 +30,7 @@ STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", 
           "fallback", "intersect", "compact", "collect", "merge", "locate"]
 # stage -> the kernel(s) it times (names as rocprofv3 prints them)
 STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1p",
-                 "hist2": "k_hist16 (or k_hist2)", "scan2": "k_hist16_off (or k_scan2)", "scatter2": "k_scatter2p",
+                 "hist2": "k_hist16 (or k_hist2)", "scan2": "k_hist16_off (or k_scan2)", "scatter2": "k_scatter2",
                  "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort2",
                  "fallback": "k_bitonic_stage", "intersect": "k_intersect", "compact": "k_scan+k_gather_cands",
                  "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact",

@@ -85,12 +85,13 @@ def _is_wide(L, D, R):
 
 
 def _check_wide(L, D, R):
-    """geometries of the wide path (kr_wide_run): `left` and `right` in one key each"""
+    """geometries of the wide path (kr_wide_run): flanks of up to WIDE_MAX_FLANK bases (one key each, or
+    ranked through two keys), amplicons of up to WIDE_MAX_K"""
     from . import _native
-    if not (1 <= L <= 32 and 1 <= R <= 32 and L + D + R <= _native.WIDE_MAX_K):
+    if not (1 <= L <= _native.WIDE_MAX_FLANK and 1 <= R <= _native.WIDE_MAX_FLANK and L + D + R <= _native.WIDE_MAX_K):
         raise UnsupportedGeometry(
             f"{L}/{D}/{R}: amplicons longer than 32 bases need 1 <= conserved-left, conserved-right "
-            f"<= 32 and a length <= {_native.WIDE_MAX_K}")
+            f"<= {_native.WIDE_MAX_FLANK} and a length <= {_native.WIDE_MAX_K}")
 
 
 _COMP_U8 = np.arange(256, dtype=np.uint8)

@@ -119,13 +119,13 @@ def test_geometries_beyond_the_wide_path_fail_loudly(tmp_path):
     d = os.path.join(GOLDEN, "c1")
     ing = [f"{d}/ingroup0.fasta.gz", f"{d}/ingroup1.fasta.gz"]
     with pytest.raises(KF.UnsupportedGeometry):
-        KF.find_regions(ing, [], 33, 20, 80)          # conserved-left longer than one key
+        KF.find_regions(ing, [], 65, 20, 120)         # conserved-left longer than KR_WIDE_MAX_FLANK
     with pytest.raises(KF.UnsupportedGeometry):
-        KF.find_regions(ing, [], 30, 30, 200)         # longer than KR_WIDE_MAX_K
+        KF.find_regions(ing, [], 30, 30, 300)         # longer than KR_WIDE_MAX_K
     assert KF.find_regions(ing, [], 30, 0, 60)[0] == []   # R = 0 quirk: every group fails the filter
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_WIDE_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_WIDE_SEEDS", "32"))))
 def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatch):
     """kr_wide_run (three sorts + locate) against the text-level oracle: k > 32 and D > 16,
     soft masking, N runs, repeats, several records, with and without key-space slices; every
@@ -137,6 +137,9 @@ def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatc
     rng = random.Random(7000 + seed)
     L, D, R = rng.choice([(12, 10, 12), (4, 30, 3), (6, 18, 6), (32, 5, 32), (20, 0, 20), (1, 40, 1),
                           (16, 17, 3), (9, 64, 9), (32, 64, 32), (5, 24, 8)])
+    if seed >= 16:      # flanks longer than one key (ranked through two spectra and their combinations),
+        L, D, R = [(35, 20, 35), (33, 0, 12), (10, 30, 64), (64, 100, 64), (40, 150, 33), (34, 1, 34),
+                   (48, 8, 5), (7, 60, 50)][seed % 8]          # amplicons up to KR_WIDE_MAX_K
     if seed % 4 == 3:
         monkeypatch.setenv("KR_SLICE_BASES", "1")
     if seed % 3 == 1:
