@@ -95,6 +95,12 @@ int kr_set_params(kr_ctx*, int L, int D, int R, int softmask_mode, size_t max_ba
 enum { KR_STRANDS_BOTH = 0, KR_STRANDS_FORWARD = 1, KR_STRANDS_CANONICAL = 2 };
 int kr_set_strands(kr_ctx*, int mode);
 
+/* kstream's --allow (kstream.py:696-713) on the device alphabet: only k-mers made of the bases whose bit
+ * is set (A = 1, C = 2, G = 4, T = 8) are kept -- a generalised bad-base mask in the pack kernel.  The host
+ * layer uses it when the allowed set holds no letter beyond ACGT(N) and, where both strands are emitted, is
+ * closed under complement.  After kr_set_params, before the first upload. */
+int kr_set_allow(kr_ctx*, unsigned base_mask);
+
 /* H2D copy of one genome's text + all device allocations it needs. */
 int kr_genome_upload(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
 /* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous. */
@@ -107,6 +113,10 @@ int64_t kr_genome_count(kr_ctx*, int genome_id);               /* syncs */
  * only.  Lets mergeFiles (intersectAmplicons.py:232) run on files.  Returns n. */
 int64_t kr_genome_load_sorted(kr_ctx*, int genome_id, const uint64_t* keys, size_t n);
 int64_t kr_genome_fetch_keys(kr_ctx*, int genome_id, uint64_t* out, size_t cap);
+/* kstream WITHOUT --sort (kstream.py:327-405): the keys of an uploaded genome in stream order -- window
+ * by window, a window's reverse complement right after it (KR_STRANDS_BOTH) -- no sort involved.
+ * Returns the number of keys (<= 2 n_bases). */
+int64_t kr_genome_keys_in_order(kr_ctx*, int genome_id, uint64_t* out, size_t cap);
 int     kr_genome_free(kr_ctx*, int genome_id);
 
 /* n-way intersection on the (left,right) prefix over sorted genomes.

@@ -51,6 +51,8 @@ SYMBOLS = [
     ("kr_genome_count", _c.c_int64, [_P, _c.c_int]),
     ("kr_genome_load_sorted", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_genome_fetch_keys", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
+    ("kr_genome_keys_in_order", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
+    ("kr_set_allow", _c.c_int, [_P, _c.c_uint]),
     ("kr_genome_free", _c.c_int, [_P, _c.c_int]),
     ("kr_intersect", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_cands_count", _c.c_int64, [_P]),
@@ -280,6 +282,17 @@ class Engine:
         n = self.count(gid)
         out = np.empty(max(n, 1), dtype=np.uint64)
         self._check(self.lib.kr_genome_fetch_keys(self.ctx, gid, _ptr(out), n), "kr_genome_fetch_keys")
+        return out[:n]
+
+    def set_allow(self, bases):
+        """kstream --allow on the device alphabet: an iterable of the bases (of ACGT) a k-mer may hold"""
+        mask = sum(1 << "ACGT".index(b) for b in set(bases))
+        self._check(self.lib.kr_set_allow(self.ctx, mask), "kr_set_allow")
+
+    def keys_in_order(self, gid, n_bases):
+        """keys of an uploaded genome in stream order (no sort)"""
+        out = np.empty(max(2 * n_bases, 1), dtype=np.uint64)
+        n = self._check(self.lib.kr_genome_keys_in_order(self.ctx, gid, _ptr(out), len(out)), "kr_genome_keys_in_order")
         return out[:n]
 
     def free(self, gid):

@@ -2,15 +2,17 @@
 
 Same constructor, iteration, call and write() contract as the reference class
 (kstream/kstream.py:122-428) and the same `kstream` command line
-(kstream.py:835-952).  Sorted single-k streams run on the GPU through
+(kstream.py:835-952).  k-mer streams of k <= 32 run on the GPU through
 libkrisp_hip.so (`kstream.device_plan`): the option combination krisp_fasta uses
 (krisp_fasta.py:21-43: kmers=k, complements, disallow="Nn", omitsoft|mapsoft,
 split=[L,-R], sort with sortcols=[0,2]) and its neighbours -- forward strand only or
 canonicals instead of complements, no split or a one-sided split, sort columns that
-leave the fields in line order.  No CPU sort or k-mer generation stands in for that
-route when the library is missing: it raises.  Option sets outside it (allow,
-expand-iupac, several k, unsorted streaming, kept lower case, other column orders) are
-outside the accelerated hot path and are served by the plain host
+leave the fields in line order, several k (one device sort per k, the sorted streams
+merged), --allow of plain bases (a base mask in the pack kernel), and no sort at all
+(keys in stream order, kr_genome_keys_in_order).  No CPU sort or k-mer generation stands
+in for that route when the library is missing: it raises.  Option sets outside it
+(expand-iupac, kept lower case, other column orders, --allow of ambiguity letters, k > 32)
+are outside the accelerated hot path and are served by the plain host
 generator chain below, as are inputs holding characters the 2-bit alphabet cannot carry
 under the forward / canonical modes.
 """
@@ -92,7 +94,8 @@ class kstream:
     def device_geometry(self):
         """(L, D, R) when this option set is THE krisp_fasta combination (krisp_fasta.py:21-43)."""
         plan = self.device_plan()
-        if plan is None or plan["strands"] != 0 or plan["layout"] != "lrd" or len(plan["fields"]) != 3:
+        if (plan is None or plan.get("multi") or plan["strands"] != 0 or plan["layout"] != "lrd"
+                or len(plan["fields"]) != 3 or not plan["sorted"] or plan["allow"] is not None):
             return None
         return plan["geometry"]
 
@@ -109,16 +112,38 @@ class kstream:
           layout 'lrd'  first | last | middle field    -> engine geometry (first, middle, last)
         Everything else the reference supports (allow, expand-iupac, several k, unsorted streaming,
         other column orders, keeping lower case) stays on the host chain."""
-        if self.kmers is None or len(self.kmers) != 1:
+        if self.kmers is None or len(self.kmers) < 1:
             return None
-        k = self.kmers[0]
+        if len(self.kmers) > 1:
+            # several k: one device plan (one sort) per k, the sorted streams merged by the same
+            # comparator (unsorted, the windows of every record come k by k: host chain)
+            if self.sort is not True:
+                return None
+            plans = [self._plan_one(k) for k in self.kmers]
+            if any(p is None for p in plans):
+                return None
+            return dict(multi=plans, strands=plans[0]["strands"], layout="multi", fields=None, geometry=None)
+        return self._plan_one(self.kmers[0])
+
+    def _plan_one(self, k):
         if not (1 <= k <= 32):
             return None
-        if self.allow is not None or self.expandiupac or self.disallow != {"N", "n"}:
-            return None
-        if self.omitsoft == self.mapsoft or self.sort is not True:
+        if self.expandiupac or self.omitsoft == self.mapsoft or self.sort not in (True, False):
             return None
         strands = 0 if self.complements else (2 if self.canonicals else 1)
+        # --allow (kstream.py:696-713) of plain bases = a base mask on the device; letters the 2-bit
+        # alphabet cannot carry in the allowed set (ambiguity codes, '-', ...) stay on the host chain.
+        # Both strands are emitted BEFORE the allow filter: the set must be closed under complement
+        allow_bases = None
+        if self.allow is not None:
+            if not self.allow <= set("ACGTNacgtn"):
+                return None
+            allow_bases = "".join(sorted(self.allow & set("ACGT")))
+            if strands == 0 and {COMP_MAP[b] for b in allow_bases} != set(allow_bases):
+                return None
+        n_survives = self.allow is None or "N" in self.allow
+        if self.disallow != {"N", "n"} and not (self.disallow is None and not n_survives):
+            return None
         # fields of the output line (kstream.py:805-832)
         if self.split is None:
             fields = [k]
@@ -135,6 +160,10 @@ class kstream:
                 if b > 0 or a - b > k:
                     return None
                 fields = [a, 0, k - a] if b == 0 else [a, k - a + b, -b]     # kstream.py:824-830
+        if self.sort is False:
+            # stream order: the window as it is, cut into its fields
+            return dict(k=k, fields=fields, layout="ldr", geometry=(k, 0, 0), strands=strands, sorted=False,
+                        allow=allow_bases)
         # effective order of the fields: listed columns, then line order
         cols = [] if self.sortcols is None else list(self.sortcols)
         if any((not isinstance(c, int)) or c < 0 or c >= len(fields) for c in cols):
@@ -153,35 +182,76 @@ class kstream:
             return None
         if geometry[1] > 16:
             return None
-        return dict(k=k, fields=fields, layout=layout, geometry=geometry, strands=strands)
+        return dict(k=k, fields=fields, layout=layout, geometry=geometry, strands=strands, sorted=True,
+                    allow=allow_bases)
 
     def _device_keys(self, sequences, plan):
         """-> (sorted keys, is_rna, IUPAC k-mers as field tuples) or None when the input holds
         characters the device alphabet cannot carry in a way only the host chain reproduces."""
         from . import _native
         L, D, R = plan["geometry"]
-        krisp_combo = plan["strands"] == 0 and plan["layout"] == "lrd" and len(plan["fields"]) == 3
+        krisp_combo = (plan["strands"] == 0 and plan["layout"] == "lrd" and len(plan["fields"]) == 3
+                       and plan["sorted"])
+        allow = plan.get("allow")
         if krisp_combo:
-            bases, rna, windows = fasta.ingest(sequences, plan["k"], self.omitsoft)
-            special = [codec.split_window(w, L, D, R) for w in windows]
+            bases, rna, windows = fasta.ingest(sequences, plan["k"], self.omitsoft)    # (KeyError as the reference)
+            # (--allow of plain bases drops every k-mer that holds an ambiguity letter)
+            special = [] if allow is not None else [codec.split_window(w, L, D, R) for w in windows]
         else:
-            # forward / canonical strands, other layouts: anything outside ACGTNacgtn (IUPAC
-            # letters are kept by the reference, other characters pass or raise depending on
-            # the strand option) goes to the host chain as a whole
+            # forward / canonical strands, other layouts, stream order: anything outside ACGTNacgtn
+            # (IUPAC letters are kept by the reference, other characters pass or raise depending on
+            # the strand option) goes to the host chain as a whole -- unless --allow drops those
+            # k-mers anyway and no reverse complement is formed before it does
             bases, rna, nspecial = fasta.load_any(sequences)
-            if nspecial:
+            if nspecial and not (allow is not None and plan["strands"] != 0):
                 return None
             special = []
         with _native.Engine(device=self.device) as eng:
             eng.set_params(L, D, R, omit_soft=self.omitsoft, max_bases=len(bases))
             if plan["strands"]:
                 eng.set_strands(plan["strands"])
-            eng.add(0, bases)
-            keys = eng.keys(0).copy()
+            if allow is not None:
+                eng.set_allow(allow)
+            if plan["sorted"]:
+                eng.add(0, bases)
+                keys = eng.keys(0).copy()
+            else:
+                eng.upload(0, bases)
+                keys = eng.keys_in_order(0, len(bases))
         return keys, rna, special
 
     def _device_blocks(self, sequences, plan):
-        """-> (iterator of byte blocks of the sorted output, line count) or None"""
+        """-> (iterator of byte blocks of the output, line count) or None"""
+        if plan.get("multi"):
+            # several k: every k sorted on the device, the streams merged under the one comparator
+            # of `sort -t, -kN,N ...` (listed columns, then the whole line)
+            import heapq
+            streams, total = [], 0
+            for sub in plan["multi"]:
+                got = self._device_blocks(sequences, sub)
+                if got is None:
+                    return None
+                streams.append(b"".join(got[0]).split(b"\n")[:-1])
+                total += got[1]
+            cols = self.sortcols
+
+            def key(ln):
+                if cols is None:
+                    return (ln,)
+                f = ln.split(b",")
+                return tuple(f[c] if c < len(f) else b"" for c in cols) + (ln,)
+            merged = heapq.merge(*streams, key=key)
+
+            def blocks():
+                buf = []
+                for ln in merged:
+                    buf.append(ln)
+                    if len(buf) >= 1 << 16:
+                        yield b"\n".join(buf) + b"\n"
+                        buf = []
+                if buf:
+                    yield b"\n".join(buf) + b"\n"
+            return blocks(), total
         got = self._device_keys(sequences, plan)
         if got is None:
             return None

@@ -231,6 +231,50 @@ def test_kstream_accelerated_combination(case, tmp_path):
         assert list(ks(src)) == case["out"]
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_kstream_device_routes_equal_the_host_chain_on_random_inputs(seed, tmp_path):
+    """several k, --allow of plain bases, stream order (no sort), strand modes, splits: what the
+    device serves must be, line for line, what the plain generator chain (pinned to the reference
+    by its vectors) yields -- including the exceptions"""
+    import random
+    from krisp_amd.kstream import kstream
+    rng = random.Random(9100 + seed)
+    alphabet = rng.choice(["ACGT", "ACGTacgtN", "ACGTACGTACGTacgtNnR", "AACCGGTTn-"])
+    recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 400))) for _ in range(rng.randint(1, 5))]
+    text = "".join(f">r{i}\n{r}\n" for i, r in enumerate(recs))
+    src = str(tmp_path / "x.fa")
+    open(src, "w").write(text)
+    kw = dict(mapsoft=True) if rng.random() < 0.6 else dict(omitsoft=True)
+    mode = seed % 4
+    if mode == 0:                                   # several k, sorted
+        kw.update(kmers=sorted(rng.sample(range(3, 20), rng.randint(2, 3))), sort=True, disallow="Nn",
+                  complements=rng.random() < 0.6)
+        if rng.random() < 0.5:
+            kw.update(split=[2], sortcols=rng.choice([None, [0], [0, 1]]))
+    elif mode == 1:                                 # --allow
+        kw.update(kmers=rng.randint(3, 24), sort=True, allow=rng.choice(["ACGT", "ACGTN", "AT", "CG", "ACGTacgt"]),
+                  disallow=rng.choice(["Nn", None]), complements=rng.random() < 0.5)
+        if kw["disallow"] is None and "N" in kw["allow"]:
+            kw["disallow"] = "Nn"
+    elif mode == 2:                                 # stream order
+        kw.update(kmers=rng.randint(2, 30), sort=False, disallow="Nn", complements=rng.random() < 0.5)
+        k = kw["kmers"]
+        if rng.random() < 0.5 and k >= 3:
+            kw.update(split=[rng.randint(1, k - 2), -1])
+    else:                                           # canonicals / forward with --allow and odd characters
+        kw.update(kmers=rng.randint(3, 20), sort=rng.random() < 0.5, allow="ACGT", disallow=None,
+                  canonicals=rng.random() < 0.5)
+    ks = kstream(**kw)
+    assert ks.device_plan() is not None, kw
+
+    def run(fn):
+        try:
+            return ("ok", list(fn(src)))
+        except Exception as e:  # noqa: BLE001
+            return ("raises", type(e).__name__)
+    assert run(ks) == run(ks.host_lines), kw
+
+
 def test_readme_known_answers_on_the_gpu(tmp_path):
     d = os.path.join(GOLDEN, "c1")
     ing = [f"{d}/ingroup{i}.fasta.gz" for i in (0, 1)]

@@ -107,10 +107,22 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
                    dict(split=[25], sortcols=None)):
         p = kstream(**dict(base, **change)).device_plan()
         assert p["layout"] == "ldr" and p["geometry"] == (28, 0, 0), change
-    for change in (dict(kmers=33, split=[30, -2]), dict(disallow="N"), dict(mapsoft=False), dict(sort=False),
-                   dict(allow="ACGT"), dict(expandiupac=True), dict(kmers=[28, 29]), dict(sortcols=[1]),
-                   dict(sortcols=[2]), dict(sortcols=[1, 0]), dict(split=[5, -3], sortcols=[0, 2])):
+    for change in (dict(kmers=33, split=[30, -2]), dict(disallow="N"), dict(mapsoft=False),
+                   dict(expandiupac=True), dict(sortcols=[1]), dict(kmers=[28, 33]),
+                   dict(sortcols=[2]), dict(sortcols=[1, 0]), dict(split=[5, -3], sortcols=[0, 2]),
+                   dict(allow="ACGTR"), dict(allow="ACG"), dict(allow="ACGT-"), dict(kmers=[28, 29], sort=False)):
         assert kstream(**dict(base, **change)).device_plan() is None, change
+    # several k (one device sort per k, merged), --allow of plain bases (a base mask), stream order
+    p = kstream(**dict(base, kmers=[28, 29])).device_plan()
+    assert [q["k"] for q in p["multi"]] == [28, 29]
+    p = kstream(**dict(base, allow="ACGT")).device_plan()
+    assert p["allow"] == "ACGT" and p["sorted"]
+    assert kstream(**dict(base, allow="ACGTN")).device_plan()["allow"] == "ACGT"
+    assert kstream(**dict(base, allow="AT", disallow=None)).device_plan()["allow"] == "AT"
+    assert kstream(**dict(base, allow="AC", complements=False, disallow=None)).device_plan()["allow"] == "AC"
+    assert kstream(**dict(base, allow="ACGTN", disallow=None)).device_plan() is None       # N windows would survive
+    p = kstream(**dict(base, sort=False)).device_plan()
+    assert p["sorted"] is False and p["geometry"] == (28, 0, 0) and p["fields"] == [25, 1, 2]
 
 
 def test_codec_roundtrip_and_oracle_agreement():
