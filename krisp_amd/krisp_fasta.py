@@ -476,6 +476,84 @@ def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, 
 # ----------------------------------------------------------------------------
 # stage functions (reference signatures)
 # ----------------------------------------------------------------------------
+def _hit_windows(sel, text, k):
+    """member windows of kr_wide_run hits of ONE genome as an (n, k) byte matrix: cut from the text
+    the host holds, soft-mask mapped, reverse complemented for strand 1"""
+    t = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+    W = t[sel["pos"].astype(np.int64)[:, None] + np.arange(k, dtype=np.int64)] & np.uint8(0xDF)
+    rc = sel["strand"] == 1
+    W[rc] = _COMP_U8[W[rc][:, ::-1]]
+    return W
+
+
+def _extract_sorted_wide(fasta_file, L, R, k, output, omit, device, verbose):
+    """extractSortedKmers for amplicons longer than one key (krisp_fasta.py:16-66 takes any k):
+    the genome alone through kr_wide_run without a filter -- every window then belongs to a
+    (left,right) group, the groups come in (left,right) order -- and the members of a group put in
+    diag order here; lines 'left,diag,right' as kstream.py:832 writes them."""
+    from . import _native
+    Le, De, Re = codec.effective_geometry(L, k - L - R, R)
+    _check_wide(Le, De, Re)
+    bases, rna, special = fasta.ingest(fasta_file, k, omit)
+    lut = np.arange(256, dtype=np.uint8)
+    if rna:
+        lut[ord("T")] = ord("U")
+    with _native.Engine(device=device) as eng:
+        eng.set_params_wide(Le, De, Re, omit_soft=omit, max_bases=max(len(bases), 1))
+        eng.upload(0, bases)
+        nhits = eng.wide_run([0], [True], apply_filter=False)
+        hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
+    # IUPAC k-mers (kept by the reference, resolved on the host) join by a merge of sorted lines
+    sp_lines = sorted(",".join(codec.split_window(w, Le, De, Re)).encode() for w in special)
+
+    def key(ln):
+        f = ln.split(b",")
+        return (f[0], f[2], f[1])
+
+    def chunks():
+        """the hits cut at group boundaries (members of one group are ordered together), each chunk as
+        its window matrix in (group, diag) order"""
+        pos = 0
+        while pos < len(hits):
+            b = min(len(hits), pos + (1 << 20))
+            while b < len(hits) and hits["cand"][b] == hits["cand"][b - 1]:
+                b += 1
+            sel = hits[pos:b]
+            W = _hit_windows(sel, bases, k)
+            rec = np.empty(len(sel), dtype=[("c", ">u4"), ("d", f"S{max(De, 1)}")])
+            rec["c"] = sel["cand"]
+            rec["d"] = W[:, Le:Le + De].copy().view(f"S{De}").ravel() if De else b""
+            yield W[np.argsort(rec, order=["c", "d"], kind="stable")]
+            pos = b
+
+    n = 0
+    with open(output, "wb") as f:
+        if not sp_lines:
+            for W in chunks():
+                W = lut[W]
+                out = np.empty((len(W), k + 3), dtype=np.uint8)
+                out[:, :Le] = W[:, :Le]
+                out[:, Le] = ord(",")
+                out[:, Le + 1:Le + 1 + De] = W[:, Le:Le + De]
+                out[:, Le + 1 + De] = ord(",")
+                out[:, Le + 2 + De:k + 2] = W[:, Le + De:]
+                out[:, k + 2] = ord("\n")
+                f.write(out.tobytes())
+                n += len(out)
+        else:
+            import heapq
+            dev = []
+            for W in chunks():
+                for row in W:
+                    s = bytes(row)
+                    dev.append(s[:Le] + b"," + s[Le:Le + De] + b"," + s[Le + De:])
+            tr = bytes.maketrans(b"T", b"U") if rna else None
+            for ln in heapq.merge(dev, sp_lines, key=key):
+                f.write((ln.translate(tr) if tr else ln) + b"\n")
+                n += 1
+    return n
+
+
 def extractSortedKmers(fasta_file, primer_left, primer_right, ampl_len, output,
                        sortmem, parallel=1, verbose=True, omit=True, device=0):
     """Fasta file -> sorted 'left,diag,right' k-mer file (krisp_fasta.py:16-66)."""
@@ -484,13 +562,14 @@ def extractSortedKmers(fasta_file, primer_left, primer_right, ampl_len, output,
               sortcols=[0, 2], sortnp=parallel, parallel=parallel, device=device)
     kw["omitsoft" if omit else "mapsoft"] = True
     ks = kstream(fasta_file, **kw)
-    if ks.device_geometry() is None:
-        raise UnsupportedGeometry(f"{primer_left}/{ampl_len - primer_left - primer_right}/"
-                                  f"{primer_right} is outside the device path")
     t0 = time.time()
     if verbose:
         print(f"Extracting {ampl_len}-mers from {fasta_file} and saving to {output}", file=sys.stderr)
-    found = ks.write(output)
+    if ks.device_geometry() is not None:
+        found = ks.write(output)
+    else:
+        # amplicons longer than one key: the wide path (raises UnsupportedGeometry beyond it)
+        found = _extract_sorted_wide(fasta_file, primer_left, primer_right, ampl_len, output, omit, device, verbose)
     if verbose:
         print(f"=> Extracted and sorted {found:,} {ampl_len}-kmers from {fasta_file} in "
               f"{prettyTime(time.time() - t0)}", file=sys.stderr)
@@ -543,8 +622,16 @@ def mergeFiles(files, output, parallel=1, workdir=None, verbose=True, device=0):
         open(output, "w").close()
         return
     L, D, R = geo
-    _check_geometry(L, D, R)
     labels = [simplename(f) for f in files]
+    if _is_wide(L, D, R):
+        groups = _merge_files_wide(contents, labels, L, D, R, device)
+        with open(output, "w") as f:
+            for ln in amplicon.merged_lines(groups):
+                f.write(ln + "\n")
+        if verbose:
+            print(f"=> Merged {len(files)} files -> {output} in {prettyTime(time.time() - t0)}", file=sys.stderr)
+        return
+    _check_geometry(L, D, R)
     keysets, specials = [], []
     for lines in contents:
         flat = b"".join(lines)
@@ -577,6 +664,36 @@ def mergeFiles(files, output, parallel=1, workdir=None, verbose=True, device=0):
             f.write(ln + "\n")
     if verbose:
         print(f"=> Merged {len(files)} files -> {output} in {prettyTime(time.time() - t0)}", file=sys.stderr)
+
+
+def _merge_files_wide(contents, labels, L, D, R, device):
+    """mergeFiles for k-mer files of amplicons longer than one key: every file becomes a "genome"
+    whose records are its lines (one window each, forward strand only: the file already holds both
+    strands), kr_wide_run finds the (left,right) pairs present in all files and where their members lie."""
+    from . import _native
+    _check_wide(L, D, R)
+    k = L + D + R
+    texts = []
+    for lines in contents:
+        flat = b"".join(lines)
+        rna = b"U" in flat and b"T" not in flat
+        if flat.translate(None, b"ACGTU," if rna else b"ACGT,"):
+            raise fasta.IupacWindowsUnsupported("k-mer files of amplicons longer than one key that hold IUPAC "
+                                                "ambiguity letters: use the fused flow (find_regions)")
+        rec = [ln.replace(b",", b"") for ln in lines]
+        if any(len(r) != k for r in rec):
+            raise ValueError("k-mer file with lines of different lengths")
+        t = b"\n".join(rec)
+        texts.append(np.frombuffer(t.replace(b"U", b"T") if rna else t, dtype=np.uint8))
+    ids = list(range(len(texts)))
+    with _native.Engine(device=device) as eng:
+        eng.set_params_wide(L, D, R, omit_soft=False, max_bases=max(1, max(len(t) for t in texts)))
+        eng.set_strands(_native.STRANDS_FORWARD)
+        for i, t in enumerate(texts):
+            eng.upload(i, t)
+        nhits = eng.wide_run(ids, [True] * len(ids), apply_filter=False)
+        hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
+    return _groups_from_hits(hits, texts, labels, L, D, R)
 
 
 def _parse_merged(path):
@@ -628,35 +745,43 @@ def filterAlignments(kmerfile, output, ingroup, device=0):
         if D == 0:
             keep = []                               # diagnosticLength() == 0: no column can pass
         else:
-            if D > 16:
-                raise UnsupportedGeometry(f"diagnostic length {D} > 16 exceeds the device mask format")
-            rows, host_keep = [], []
+            # the device's mask pair carries 16 columns: a group passes when ANY column separates the
+            # groups, so longer diagnostic regions are filtered 16 columns at a time and the kept sets united
+            host_keep, pure = [], []
             for gi, g in enumerate(groups):
                 if not all(_pure(a.diag) for a in g):
                     # IUPAC letters in a diagnostic column: base sets are sets of letters
                     # (Amplicon.py:514-520); rare, evaluated here
                     if amplicon.ingroup_unique_columns(g, ingroup):
                         host_keep.append(gi)
-                    continue
-                im = om = 0
-                for a in g:
-                    m = 0
-                    for c, ch in enumerate(a.diag):
-                        m |= 1 << (4 * c + _BASE_BIT[ch])
-                    for lab in set(a.labels):
-                        if lab in ingroup:
-                            im |= m
-                        else:
-                            om |= m
-                rows.append((gi, im, om))           # prefix = group index: sorted, unique
-            keep = []
-            if rows:
-                cands = np.array(rows, dtype=_native.CAND)
-                with _native.Engine(device=device) as eng:
-                    eng.set_params(1, D, 0, max_bases=64)
-                    eng.load_cands(cands)
+                else:
+                    pure.append(gi)
+            kept = set()
+            with _native.Engine(device=device) as eng:
+                for c0 in range(0, D, 16):
+                    Dc = min(16, D - c0)
+                    rows = []
+                    for gi in pure:
+                        if gi in kept:
+                            continue
+                        im = om = 0
+                        for a in groups[gi]:
+                            m = 0
+                            for c, ch in enumerate(a.diag[c0:c0 + Dc]):
+                                m |= 1 << (4 * c + _BASE_BIT[ch])
+                            for lab in set(a.labels):
+                                if lab in ingroup:
+                                    im |= m
+                                else:
+                                    om |= m
+                        rows.append((gi, im, om))           # prefix = group index: sorted, unique
+                    if not rows:
+                        break
+                    eng.set_params(1, Dc, 0, max_bases=64)
+                    eng.load_cands(np.array(rows, dtype=_native.CAND))
                     eng.merge_cands(None, apply_filter=True)
-                    keep = [int(p) for p in eng.cands()["prefix"]]
+                    kept.update(int(p) for p in eng.cands()["prefix"])
+            keep = sorted(kept)
             keep = sorted(keep + host_keep)
     with open(output, "w") as f:
         for gi in keep:

@@ -69,8 +69,11 @@ def test_cli_output_is_byte_identical_to_the_reference(case, tmp_path):
     assert open(csvp).read() == case["csv"]
 
 
-@pytest.mark.parametrize("case", PACKABLE, ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", PACKABLE + TOO_LONG, ids=lambda c: c["name"])
 def test_stage_functions_match_reference_intermediates(case, tmp_path):
+    """the reference's file-per-stage seam (krisp_fasta.py:16-66, intersectAmplicons.py:232,
+    filterAlignments.py:31): sorted k-mer files by sha256, merged and filtered files canonicalised --
+    one-key geometries and amplicons longer than one key (the wide path behind the same functions)"""
     from krisp_amd import krisp_fasta as KF
     from krisp_amd import fasta
     L, D, R = case["L"], case["D"], case["R"]
@@ -97,8 +100,7 @@ def test_stage_functions_match_reference_intermediates(case, tmp_path):
 
 @pytest.mark.parametrize("case", TOO_LONG, ids=lambda c: c["name"])
 def test_wide_amplicons_match_reference_intermediates(case, tmp_path):
-    """k > 32: the fused flow reproduces the reference's filtered (or merged) file; the
-    file-per-stage functions have no wide form and say so."""
+    """k > 32: the fused flow reproduces the reference's filtered (or merged) file"""
     from krisp_amd import amplicon
     from krisp_amd import krisp_fasta as KF
     paths = _paths(case, tmp_path)
@@ -109,9 +111,6 @@ def test_wide_amplicons_match_reference_intermediates(case, tmp_path):
     if "filtered_canon" in case:
         assert stats["candidates"] == len({tuple(ln.split(",")[0:3:2]) for ln in case["merged_canon"]})
     assert stats["kmers"] == sum(case["sorted"][f]["lines"] for f in case["ingroup"] + case["outgroup"])
-    with pytest.raises(KF.UnsupportedGeometry):
-        KF.extractSortedKmers(paths[case["ingroup"][0]], case["L"], case["R"], _amplicon(case),
-                              str(tmp_path / "x.kmers"), "80%", 1, False, case["omit_soft"])
 
 
 def test_geometries_beyond_the_wide_path_fail_loudly(tmp_path):
