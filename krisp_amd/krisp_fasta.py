@@ -381,25 +381,15 @@ class PeerFailed(RuntimeError):
     """another rank of a multi-GPU run raised; this rank stops with it instead of waiting in a collective"""
 
 
-def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,
-                             transport="rccl", verbose=False):
-    """find_regions over several GPUs: one process per GPU (started by torch.distributed.run,
-    mpirun, srun ...: RANK / LOCAL_RANK / WORLD_SIZE in the environment; no PyTorch involved).
-    Genomes are sharded round-robin over the ranks (ingroup and outgroup files interleaved so that
-    every rank can prune with the monotone filter), each rank sorts and intersects its own, the
-    candidate lists are tree-reduced between the GPUs (kr_cands_reduce: RCCL, device to device),
-    the survivors broadcast, every rank collects its genomes' records and rank 0 gathers them.
-    Returns (groups, stats) on rank 0 and (None, stats) elsewhere.  The one-key path only
-    (k <= 32, D <= 16), no IUPAC letters, no RNA: those need look-ups across all genomes and stay
-    on one GPU.  A rank that fails (missing file, illegal character, out of memory) makes every
-    rank raise before the next collective: nobody is left waiting."""
+def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft):
+    """one rank of the multi-GPU flow (see find_regions_distributed); `connect(engine)` gives the
+    engine its communicator.  Returns (groups, stats) on rank 0 and (None, stats) elsewhere."""
     from . import _native
     from . import distributed as D
     k = amplicon_len
     Le, De, Re = codec.effective_geometry(L, k - L - R, R)
     _check_geometry(Le, De, Re)
     do_filter = k > L + R
-    rank, local_rank, world = D.env_rank_world()
     # interleave ingroup / outgroup files so that a round-robin shard holds both kinds
     ing, outg = list(ingroup_files), list(outgroup_files)
     order = []
@@ -415,11 +405,9 @@ def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, 
     # find_regions does: an outgroup file whose label equals an ingroup label counts as ingroup
     ingroup_labels = frozenset(simplename(f) for f in ing)
     mine = D.shard(list(range(len(order))), rank, world)
-    if transport == "dir":                 # rehearsal: the ranks share the visible GPU(s)
-        local_rank %= max(1, int(os.environ.get("KRISP_VISIBLE_GPUS", "1")))
 
-    with _native.Engine(device=local_rank) as eng:
-        D.connect(eng, rank, world, transport=transport)
+    with _native.Engine(device=device) as eng:
+        connect(eng)
 
         def together(fn):
             """run fn() on this rank; every rank learns whether all succeeded before anyone goes on"""
@@ -471,6 +459,67 @@ def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, 
     if quirk_all_fail:
         return [], stats
     return amplicon.groups_from_records(allrec, labels, Le, De, Re), stats
+
+
+def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,
+                             transport="rccl", verbose=False):
+    """find_regions over several GPUs: one process per GPU (started by torch.distributed.run,
+    mpirun, srun ...: RANK / LOCAL_RANK / WORLD_SIZE in the environment; no PyTorch involved).
+    Genomes are sharded round-robin over the ranks (ingroup and outgroup files interleaved so that
+    every rank can prune with the monotone filter), each rank sorts and intersects its own, the
+    candidate lists are tree-reduced between the GPUs (kr_cands_reduce: RCCL, device to device),
+    the survivors broadcast, every rank collects its genomes' records and rank 0 gathers them.
+    Returns (groups, stats) on rank 0 and (None, stats) elsewhere.  The one-key path only
+    (k <= 32, D <= 16), no IUPAC letters, no RNA: those need look-ups across all genomes and stay
+    on one GPU.  A rank that fails (missing file, illegal character, out of memory) makes every
+    rank raise before the next collective: nobody is left waiting."""
+    from . import distributed as D
+    rank, local_rank, world = D.env_rank_world()
+    if transport == "dir":                 # rehearsal: the ranks share the visible GPU(s)
+        local_rank %= max(1, int(os.environ.get("KRISP_VISIBLE_GPUS", "1")))
+    return _distributed_rank(rank, world, local_rank, lambda eng: D.connect(eng, rank, world, transport=transport),
+                             ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft)
+
+
+def find_regions_multi_device(ingroup_files, outgroup_files, L, R, amplicon_len, devices, omit_soft=False,
+                              verbose=False):
+    """The same flow inside ONE process: a thread per listed device (the library calls release the
+    GIL), each with its own context and communicator -- the fallback for hosts where a launcher
+    is not at hand.  Distinct devices talk over RCCL (the unique id is passed between
+    the threads); a device listed twice makes the exchange go through files instead (RCCL refuses
+    duplicate devices): that is how a one-GPU box rehearses it.  Returns (groups, stats)."""
+    import tempfile
+    import threading
+    from . import _native
+    world = len(devices)
+    if world < 1:
+        raise ValueError("find_regions_multi_device: no device listed")
+    use_rccl = len(set(devices)) == world
+    cid = _native.comm_unique_id() if use_rccl else None
+    results, errors = [None] * world, [None] * world
+    with tempfile.TemporaryDirectory(prefix="krisp_comm_") as td:
+        def connect_for(rank):
+            if use_rccl:
+                return lambda eng: eng.comm_init(rank, world, cid)
+            return lambda eng: eng.comm_init_dir(rank, world, td)
+
+        def work(rank):
+            try:
+                results[rank] = _distributed_rank(rank, world, devices[rank], connect_for(rank), ingroup_files,
+                                                  outgroup_files, L, R, amplicon_len, omit_soft)
+            except BaseException as e:  # noqa: BLE001
+                errors[rank] = e
+        threads = [threading.Thread(target=work, args=(r,), name=f"krisp-gpu{devices[r]}") for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    real = [e for e in errors if e is not None and not isinstance(e, PeerFailed)]
+    if real or any(errors):
+        raise (real or [e for e in errors if e is not None])[0]
+    groups, stats = results[0]
+    stats["kmers"] = int(sum(r[1]["kmers"] for r in results))
+    return groups, stats
 
 
 # ----------------------------------------------------------------------------
@@ -826,6 +875,9 @@ def build_parser():
     p.add_argument("--max_end_gc", type=int, default=4, metavar="INT")
     p.add_argument("--verbose", action="store_true", help="Print runtime information to sys.stderr")
     p.add_argument("--device", type=int, default=0, metavar="INT", help="GPU to run on (default: 0)")
+    p.add_argument("--devices", type=str, default=None, metavar="LIST",
+                   help="several GPUs from ONE process, e.g. 0,1,2,3: genomes sharded over them, candidate lists "
+                        "tree-reduced over RCCL (or start one process per GPU with torch.distributed.run / mpirun)")
     return p
 
 
@@ -877,7 +929,13 @@ def main(argv=None):
         for i, f in enumerate(args.outgroup):
             print(f"({i}) {f}", file=sys.stderr)
         print(file=sys.stderr)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    devices = [int(x) for x in str(args.devices).split(",")] if getattr(args, "devices", None) else None
+    if devices and len(devices) > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # one process, a thread per device
+        groups, stats = find_regions_multi_device(args.files, args.outgroup, args.conserved_left,
+                                                  args.conserved_right, args.amplicon, devices,
+                                                  omit_soft=args.omit_soft, verbose=args.verbose)
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # one process per GPU (python -m torch.distributed.run ... -m krisp_amd.krisp_fasta ...)
         groups, stats = find_regions_distributed(args.files, args.outgroup, args.conserved_left,
                                                  args.conserved_right, args.amplicon, omit_soft=args.omit_soft,

@@ -360,6 +360,19 @@ def test_ranks_sharing_the_gpu_run_the_library_exchange(world, tmp_path):
     assert "GPU_DIST_OK" in outs[0], outs[0]
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_krisp_fasta_over_several_devices_from_one_process(devices, tmp_path):
+    """--devices: a thread per listed device inside one process (here the same GPU listed again: the
+    exchange then goes through files) -- the reference's output, byte for byte"""
+    case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
+    paths = _paths(case, tmp_path)
+    aln = str(tmp_path / "a.txt")
+    csv = _run_main([paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
+                    + case["main_args"] + ["--out_align", aln, "--devices", devices])
+    assert csv == case["csv"]
+    assert open(aln).read() == case["align"]
+
+
 def test_rccl_communicator_at_world_size_one():
     """RCCL itself on this box: unique id, ncclCommInitRank, all-reduce, barrier, and the exchange
     calls (no partner: they return at once) -- what a one-GPU box can exercise of the RCCL transport"""
