@@ -40,6 +40,7 @@
 #include "h_wide.inc"        // kr_wide_run
 #include "h_ingest.inc"      // file -> inflate -> parse -> pinned upload buffer (host side)
 #include "h_comm.inc"        // multi-GPU exchange: RCCL (or files, for rehearsal) tree reduction of candidates, gather of records
+#include "h_text.inc"        // FASTA text parser, IUPAC side-channel scan (host only, no HIP)
 #include "h_misc.inc"        // timers, debug entries, FASTA text parser
 
 }  // extern "C"

@@ -1,0 +1,68 @@
+// Host-only build of the library's text code (krisp_amd/csrc/h_text.inc: FASTA parser, IUPAC
+// side-channel scan) under AddressSanitizer + UBSan, driven with random and adversarial inputs.
+// Built and run by tests/test_host_glue.py::test_text_code_under_address_sanitizer (g++; the GPU
+// cannot run sanitizers on this pool).  Every output buffer is allocated at exactly the size
+// the C ABI documents, so an overrun of one byte is an ASan report.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "krisp_hip.h"
+
+static thread_local std::string g_last_error;
+extern "C" {
+#include "../../krisp_amd/csrc/h_text.inc"
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return (uint32_t)(rng_state >> 11);
+}
+
+int main() {
+    const char* alphabets[] = {"ACGT", "ACGTacgtNn\n", "ACGTACGT>\n\r \t", "ACGTURYKMSWBDHVXx-.\n>", "\n\n>\r\n"};
+    long checks = 0;
+    for (int it = 0; it < 20000; it++) {
+        const char* al = alphabets[rnd() % 5];
+        const size_t na = strlen(al);
+        const size_t n = rnd() % (it % 50 == 0 ? 5000 : 200);
+        std::vector<uint8_t> text(n);
+        for (auto& c : text) c = (uint8_t)al[rnd() % na];
+        if (it % 7 == 0 && n > 3) text[rnd() % n] = (uint8_t)(rnd() & 0xFF);     // any byte at all
+        for (int universal = 0; universal < 2; universal++)
+            for (int one_shot = 0; one_shot < 2; one_shot++) {
+                std::vector<uint8_t> out(n + 1);                      // "out needs n + 1 bytes"
+                int64_t stats[4];
+                const int64_t m = kr_fasta_to_bases(n ? text.data() : nullptr, n, universal, one_shot, out.data(), out.size(), stats);
+                if (m < 0 || (size_t)m > n) { printf("bad length %lld for n %zu\n", (long long)m, n); return 1; }
+                // too small a buffer is refused, not overrun
+                if (n && kr_fasta_to_bases(text.data(), n, universal, one_shot, out.data(), n, stats) != KR_ERR_CAPACITY) return 2;
+                // the side-channel scan over what the parser produced, every k, both soft-mask rules
+                for (int k = 1; k <= 40; k += 1 + rnd() % 6)
+                    for (int omit = 0; omit < 2; omit++) {
+                        int bad = 0;
+                        const int64_t c0 = kr_scan_special(out.data(), (size_t)m, k, omit, nullptr, 0, &bad);
+                        if (c0 >= 0) {
+                            std::vector<uint64_t> st((size_t)c0);            // exactly as many as announced
+                            const int64_t c1 = kr_scan_special(out.data(), (size_t)m, k, omit, st.data(), st.size(), &bad);
+                            if (c1 != c0) { printf("count changed %lld -> %lld\n", (long long)c0, (long long)c1); return 3; }
+                            for (uint64_t s : st)
+                                if (s + (uint64_t)k > (uint64_t)m) { printf("window beyond the buffer\n"); return 4; }
+                            if (c0 > 1 && !std::is_sorted(st.begin(), st.end())) return 5;
+                        } else if (c0 != KR_ERR_KEY && c0 != KR_ERR_HOST) {
+                            return 6;
+                        }
+                        checks++;
+                    }
+            }
+    }
+    printf("ASAN_HOST_OK %ld scans\n", checks);
+    return 0;
+}
