@@ -412,3 +412,19 @@ def test_scan_special_through_the_abi_equals_the_python_scan():
     # bytes >= 0x80 are left to the host layer
     b = np.frombuffer("ACGR\xe9ACGT".encode("latin-1"), dtype=np.uint8)
     assert _native.scan_special_starts(b, 3, False) is None
+
+
+def test_text_code_under_address_sanitizer(tmp_path):
+    """the library's host-only text code (FASTA parser, side-channel scan) built alone with
+    g++ -fsanitize=address,undefined and driven with random / adversarial inputs at exactly the
+    buffer sizes the C ABI documents (GPU sanitizers do not run on this pool)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "asan_host")
+    src = os.path.join(ROOT, "tests", "native", "asan_host.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(ROOT, "include"), "-o", exe, src])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ASAN_HOST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
