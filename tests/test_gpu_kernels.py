@@ -205,6 +205,54 @@ def test_options_are_checked(N, monkeypatch):
         assert e.inversions(0) == 0                          # (KR_DBG=64 used to skip the sort)
 
 
+def test_hard_limits_fail_loudly(N):
+    """the library's caps are errors with a message, never silent truncation: genomes of 2^32 bases,
+    more keys in one sort unit than a buffer descriptor spans, more genomes than one intersect call
+    takes, geometries beyond the key and mask formats"""
+    with N.Engine() as e:
+        with pytest.raises(N.KrispHipError, match="2\\^32"):
+            e.set_params(25, 1, 2, max_bases=(1 << 32) - 10)
+        with pytest.raises(N.KrispHipError):
+            e.set_params(20, 1, 12, max_bases=1000)              # k = 33
+        with pytest.raises(N.KrispHipError):
+            e.set_params(5, 17, 5, max_bases=1000)               # D > 16
+        e.set_option(N.OPT_SLICE_BASES, 0)
+        with pytest.raises(N.KrispHipError, match="buffer descriptor"):
+            e.set_params(25, 1, 2, max_bases=300_000_000)        # 6e8 keys forced into one sort unit
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=1000)
+        with pytest.raises(N.KrispHipError, match="exceeds max_bases"):
+            e.upload(0, np.full(2000, 65, dtype=np.uint8))
+        text = _rand_text(3, 600, b"ACGT", records=1)
+        for i in range(33):
+            e.add(i, text)
+        ids = np.arange(33, dtype=np.int32)
+        flags = np.ones(33, dtype=np.uint8)
+        rc = e.lib.kr_intersect(e.ctx, N._ptr(ids), 33, N._ptr(flags), 0)       # (Engine.intersect cascades instead)
+        assert rc == -2 and b"at most 32 genomes" in e.lib.kr_last_error(e.ctx)
+        assert e.intersect(list(range(33)), [True] * 33, apply_filter=False) > 0
+    with N.Engine() as e:
+        with pytest.raises(N.KrispHipError):
+            e.set_params_wide(65, 10, 20, max_bases=1000)        # flank > KR_WIDE_MAX_FLANK
+        with pytest.raises(N.KrispHipError):
+            e.set_params_wide(30, 250, 30, max_bases=1000)       # amplicon > KR_WIDE_MAX_K
+
+
+def test_more_oversized_buckets_than_the_list_holds(N, K):
+    """150 tandem repeats of distinct 28-base units, 3000 copies each: thousands of fine buckets of
+    3000 equal keys.  More than the per-workgroup notes and the 4096-entry overflow list hold: the
+    sort falls back to tile sort + merge rounds over the whole array, and is still exact"""
+    rng = np.random.default_rng(77)
+    parts = []
+    for _ in range(150):
+        unit = b"ACGT"[0:0] + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=28))
+        parts.append(unit * 3000)
+        parts.append(bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=200)))
+    text = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    info = _check_sorted(N, K, text, 25, 1, 2)
+    assert info["overflow_segments"] >= 1 and info["fallback_launches"] > 0
+
+
 def test_key_space_slices_report(N):
     """KR_SLICE_BASES=n forces 4^n key-space slices (the large-genome path) through every test."""
     import os
