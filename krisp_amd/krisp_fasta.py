@@ -865,7 +865,7 @@ def build_parser():
                    help="Write results to as a CSV (comma-separated value) file. (default: print to screen (stdout))")
     p.add_argument("-w", "--workdir", type=str, metavar="PATH", help="Work directory to place temporary files")
     p.add_argument("-p", "--primer3", action=argparse.BooleanOptionalAction,
-                   help="Design primers with Primer3 (not available in this build)")
+                   help="Design primers with Primer3 for every region found (needs the primer3-py package)")
     p.add_argument("--tm", type=int, nargs=2, metavar="INT", default=[53, 68])
     p.add_argument("--gc", type=int, nargs=2, metavar="INT", default=[40, 70])
     p.add_argument("--amp_size", type=int, nargs=2, metavar="INT", default=[70, 150])
@@ -917,9 +917,11 @@ def main(argv=None):
     args = parser.parse_args(sys.argv[1:] if argv is None else argv)
     args = deduce_geometry(args, parser)
     if args.primer3:
-        print("ERROR: --primer3 needs primer3-py, which this build does not bundle "
-              "(Primer3 design is outside the accelerated path)", file=sys.stderr)
-        sys.exit(2)
+        from . import primers
+        if not primers.available():
+            print("ERROR: --primer3 needs the primer3-py package, which is not installed here "
+                  "(the k-mer path itself does not use it)", file=sys.stderr)
+            sys.exit(2)
     t0 = time.time()
     if args.verbose:
         print("Finding kmer-based diagnostic regions for:", file=sys.stderr)
@@ -950,7 +952,13 @@ def main(argv=None):
     if args.verbose:
         print("\nRendering output ... ", file=sys.stderr)
     ingroup = [simplename(f) for f in args.files] if len(args.outgroup) else None
-    csv_text, align_text = amplicon.render(groups, ingroup, dot=args.dot_alignment)
+    if args.primer3:
+        from . import primers
+        p3 = primers.settings(**{k: getattr(args, k) for k in ("tm", "gc", "amp_size", "primer_size", "max_sec_tm",
+                                                              "gc_clamp", "max_end_gc")})
+        csv_text, align_text = primers.render(groups, ingroup, p3, dot=args.dot_alignment)
+    else:
+        csv_text, align_text = amplicon.render(groups, ingroup, dot=args.dot_alignment)
     if args.out_csv is not None:
         with open(args.out_csv, "w") as f:
             f.write(csv_text)

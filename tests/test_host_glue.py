@@ -428,3 +428,37 @@ def test_text_code_under_address_sanitizer(tmp_path):
                            "-I" + os.path.join(ROOT, "include"), "-o", exe, src])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ASAN_HOST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_primer3_hook_with_a_stand_in_package(monkeypatch):
+    """--primer3 (krisp_amd/primers.py): primer3-py is not in this image, so the hook is driven with a
+    stand-in `primer3` module that records its calls: the template is the ingroup consensus, the target
+    the diagnostic region, groups without a pair are left out, the CSV gets the reference's columns"""
+    import sys
+    import types
+    from krisp_amd import primers
+    calls = []
+
+    def design_primers(seq_args, global_args):
+        calls.append((seq_args, global_args))
+        if seq_args["SEQUENCE_TEMPLATE"].startswith("TTTT"):
+            return {"PRIMER_PAIR_NUM_RETURNED": 0}
+        out = {"PRIMER_PAIR_NUM_RETURNED": 1, "PRIMER_LEFT_0": (0, 4), "PRIMER_RIGHT_0": (11, 4)}
+        for t in primers.CSV_TAGS:
+            out[t] = "ACGT" if t.endswith("SEQUENCE") else 1.5
+        return out
+    fake = types.ModuleType("primer3")
+    fake.bindings = types.SimpleNamespace(design_primers=design_primers)
+    monkeypatch.setitem(sys.modules, "primer3", fake)
+    assert primers.available()
+    A = amplicon.Amplicon
+    groups = [[A("ACGTA", "C", "GGATC", ["inA"]), A("ACGTA", "T", "GGATC", ["outX"])],
+              [A("TTTTA", "C", "GGATC", ["inA"]), A("TTTTA", "G", "GGATC", ["outX"])]]
+    csv, align = primers.render(groups, ["inA"], primers.settings(primer_size=(18, 30)))
+    assert len(calls) == 2 and calls[0][0] == {"SEQUENCE_TEMPLATE": "ACGTACGGATC", "SEQUENCE_TARGET": [5, 1]}
+    assert calls[0][1]["PRIMER_OPT_SIZE"] == 24 and calls[0][1]["PRIMER_PRODUCT_SIZE_RANGE"] == [(80, 300)]
+    rows = csv.split("\n")
+    assert rows[0].startswith("left_seq,diag_seq,right_seq,pair_product_size,pair_penalty,left_sequence,right_sequence")
+    assert len(rows) == 3 and rows[1].startswith("ACGTA,C,GGATC,1.5,1.5,ACGT,ACGT")      # the TTTT group has no pair
+    assert "Forward" not in align.split("\n")[0] and "Primer statistics:" in align and "Pair statistics:" in align
+    assert align.count(" : inA") == 1
