@@ -188,7 +188,9 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
        KR_WIDE_DICT_RIGHT = 1,  /* u64: rights present in all genomes, sorted (R > 32: likewise) */
        KR_WIDE_GROUPS = 2,      /* u64: composite keys of the groups present in all genomes (before the filter) */
        KR_WIDE_HITS = 3,        /* kr_wide_hit */
-       KR_WIDE_COUNTS = 4 };    /* u64 per genome of the last run: its k-mer records (2 x valid windows) */
+       KR_WIDE_COUNTS = 4,      /* u64 per genome of the last run: its k-mer records (2 x valid windows) */
+       KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
+                                   one-sector slot table in the last run, 0 = looked up through index + sorted keys */
 int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* returns #elements; out == NULL: size query */
 
 /* Host-side ingest (no GPU involved): the text of a FASTA / sequence-per-line file -> the
@@ -229,7 +231,8 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
        KR_OPT_GENERIC_INTERSECT = 2, /* 1: every intersect sub-tile takes the generic path (key-count
                                         splits, ranges from the prefixes) instead of whole-bucket sub-tiles */
        KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4 */
-       KR_OPT_ABLATE = 4 };          /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
+       KR_OPT_ABLATE = 4,            /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
+       KR_OPT_WIDE_SLOTS = 5 };      /* wide path: 1 (default) dictionaries also as one-sector slot tables, 0 index + sorted keys only */
 int     kr_set_option(kr_ctx*, int option, int64_t value);
 
 int     kr_sync(kr_ctx*);

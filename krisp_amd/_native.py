@@ -17,13 +17,13 @@ LIB_PATH = os.environ.get("KRISP_HIP_LIB") or os.path.join(HERE, "libkrisp_hip.s
 CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
-WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS = 0, 1, 2, 3, 4
+WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS, WIDE_SLOT_BITS = 0, 1, 2, 3, 4, 5
 WIDE_MAX_K = 256
 WIDE_MAX_FLANK = 64
 COMM_ID_BYTES = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
-OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE = 1, 2, 3, 4
+OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE, OPT_WIDE_SLOTS = 1, 2, 3, 4, 5
 ERR_KEY, ERR_HOST = -5, -6
 STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
@@ -244,7 +244,7 @@ class Engine:
 
     # ---- configuration
     def set_option(self, option, value):
-        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT); before set_params"""
+        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_WIDE_SLOTS); before set_params"""
         self._check(self.lib.kr_set_option(self.ctx, option, int(value)), "kr_set_option")
 
     def set_params(self, L, D, R, omit_soft=False, max_bases=0):

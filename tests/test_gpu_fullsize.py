@@ -170,18 +170,19 @@ def _groups_packed(fam, L, D, R, do_filter):
     return amplicon.groups_from_records(recs, [nm for nm, _, _ in fam], L, D, R)
 
 
-def _groups_wide(fam, L, D, R, do_filter):
+def _groups_wide(fam, L, D, R, do_filter, slots=True):
     from krisp_amd import _native
     from krisp_amd import krisp_fasta as KF
     ids = list(range(len(fam)))
     with _native.Engine() as eng:
+        eng.set_option(_native.OPT_WIDE_SLOTS, 1 if slots else 0)
         eng.set_params_wide(L, D, R, max_bases=max(len(t) for _, _, t in fam))
         for i, (_, _, t) in enumerate(fam):
             eng.upload(i, t)
         n = eng.wide_run(ids, [f for _, f, _ in fam], apply_filter=do_filter)
         hits = eng.wide_fetch(_native.WIDE_HITS) if n else np.empty(0, dtype=_native.WIDE_HIT)
         info = dict(nl=len(eng.wide_fetch(_native.WIDE_DICT_LEFT)), nr=len(eng.wide_fetch(_native.WIDE_DICT_RIGHT)),
-                    ng=len(eng.wide_fetch(_native.WIDE_GROUPS)))
+                    ng=len(eng.wide_fetch(_native.WIDE_GROUPS)), slot_bits=[int(x) for x in eng.wide_fetch(_native.WIDE_SLOT_BITS)])
     return KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R), info
 
 
@@ -207,12 +208,14 @@ def test_wide_path_equals_the_packed_path_where_both_apply(geo, length, filt, sb
 
 def test_wide_run_at_scale_properties():
     """4 x 20 Mbp, 30/40/30: every group holds every genome, groups ascend, every hit's window
-    re-read from the text carries its group's flanks; a second run returns the same hits."""
+    re-read from the text carries its group's flanks; a second run with the dictionaries looked up
+    through index + sorted keys instead of slot tables returns the same hits."""
     from krisp_amd import _native, amplicon, synth
     L, D, R = 30, 40, 30
     fam = synth.family(12, 2, 2, 20_000_000, records=16, mu=0.002, snp_every=5000)
     g1, info = _groups_wide(fam, L, D, R, True)
-    g2, _ = _groups_wide(fam, L, D, R, True)
+    g2, info2 = _groups_wide(fam, L, D, R, True, slots=False)      # (dictionary look-ups through index + sorted keys)
+    assert info["slot_bits"][0] > 0 and info["slot_bits"][3] > 0 and info["slot_bits"][6] > 0 and not any(info2["slot_bits"])
     l1 = amplicon.merged_lines(g1)
     assert l1 == amplicon.merged_lines(g2) and len(g1) > 100
     names = {nm for nm, _, _ in fam}
