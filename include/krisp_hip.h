@@ -177,7 +177,8 @@ int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
  * extractSortedKmers + mergeFiles + filterAlignments (krisp_fasta.py:237-272). */
 #define KR_WIDE_MAX_K 256
 #define KR_WIDE_MAX_FLANK 64
-/* one member window of a surviving group: cand = rank of the group in (left,right) order,
+/* one member window of a surviving group: cand = the group's number (its rank in (left,right) order
+ * under KR_OPT_WIDE_ORDERED = 1; else any number, the same for all members of a group),
  * genome = index into the genome_ids of kr_wide_run, pos = base offset of the window in the
  * uploaded text, strand = 1 when the member is the reverse complement of that window */
 typedef struct { uint32_t cand, genome, pos, strand; } kr_wide_hit;
@@ -190,7 +191,8 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
        KR_WIDE_HITS = 3,        /* kr_wide_hit */
        KR_WIDE_COUNTS = 4,      /* u64 per genome of the last run: its k-mer records (2 x valid windows) */
        KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
-                                   one-sector slot table in the last run, 0 = looked up through index + sorted keys */
+                                   one-sector slot table in the last run, 0 = looked up through index + sorted keys,
+                                   255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0) */
 int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* returns #elements; out == NULL: size query */
 
 /* Host-side ingest (no GPU involved): the text of a FASTA / sequence-per-line file -> the
@@ -232,7 +234,10 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
                                         splits, ranges from the prefixes) instead of whole-bucket sub-tiles */
        KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4 */
        KR_OPT_ABLATE = 4,            /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
-       KR_OPT_WIDE_SLOTS = 5 };      /* wide path: 1 (default) dictionaries also as one-sector slot tables, 0 index + sorted keys only */
+       KR_OPT_WIDE_SLOTS = 5,        /* wide path: 1 (default) dictionaries also as one-sector slot tables, 0 index + sorted keys only */
+       KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
+                                        of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
+                                        ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */
 int     kr_set_option(kr_ctx*, int option, int64_t value);
 
 int     kr_sync(kr_ctx*);

@@ -117,19 +117,20 @@ def _groups_from_hits(hits, texts, labels, L, D, R):
         W = t[sel["pos"].astype(np.int64)[:, None] + ar] & np.uint8(0xDF)
         rc = sel["strand"] == 1
         W[rc] = _COMP_U8[W[rc][:, ::-1]]
-        row = np.empty((len(sel), k + 8), dtype=np.uint8)
-        row[:, 0:4] = sel["cand"].astype(">u4").view(np.uint8).reshape(-1, 4)
-        row[:, 4:4 + L] = W[:, :L]
-        row[:, 4 + L:4 + L + R] = W[:, L + D:]
-        row[:, 4 + L + R:4 + k] = W[:, L:L + D]
-        row[:, 4 + k:] = np.full(len(sel), gi, dtype=">u4").view(np.uint8).reshape(-1, 4)
+        # rows order as the reference's merged file does: (left, right) groups, sequences by diag inside
+        # (the device's group numbers need not ascend with (left, right): KR_OPT_WIDE_ORDERED)
+        row = np.empty((len(sel), k + 4), dtype=np.uint8)
+        row[:, 0:L] = W[:, :L]
+        row[:, L:L + R] = W[:, L + D:]
+        row[:, L + R:k] = W[:, L:L + D]
+        row[:, k:] = np.full(len(sel), gi, dtype=">u4").view(np.uint8).reshape(-1, 4)
         rows.append(row)
     uniq, counts = np.unique(np.concatenate(rows), axis=0, return_counts=True)
     groups, last_cand, last_seq = [], None, None
     for row, cnt in zip(uniq, counts):
-        cand = bytes(row[0:4])
-        seq = bytes(row[4:4 + k])
-        gi = int.from_bytes(bytes(row[4 + k:]), "big")
+        cand = bytes(row[0:L + R])
+        seq = bytes(row[0:k])
+        gi = int.from_bytes(bytes(row[k:]), "big")
         if cand != last_cand:
             groups.append([])
             last_cand, last_seq = cand, None
@@ -548,6 +549,7 @@ def _extract_sorted_wide(fasta_file, L, R, k, output, omit, device, verbose):
     if rna:
         lut[ord("T")] = ord("U")
     with _native.Engine(device=device) as eng:
+        eng.set_option(_native.OPT_WIDE_ORDERED, 1)       # (the chunks below rely on hits in (left, right) group order)
         eng.set_params_wide(Le, De, Re, omit_soft=omit, max_bases=max(len(bases), 1))
         eng.upload(0, bases)
         nhits = eng.wide_run([0], [True], apply_filter=False)

@@ -145,6 +145,8 @@ def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatc
         monkeypatch.setenv("KR_WIDE_CACHE", "0")      # composite keys re-generated by the locate pass
     if seed % 5 == 2:
         monkeypatch.setenv("KR_WIDE_SLOTS", "0")      # dictionaries as index + sorted keys only (no slot tables)
+    if seed % 2 == 1:
+        monkeypatch.setenv("KR_WIDE_ORDERED", "1")    # order-preserving ranks instead of minimizer-bucket numbers
     n_in, n_out = rng.randint(1, 3), rng.randint(0, 2)
     if n_in + n_out == 1:
         n_out = 1

@@ -170,12 +170,13 @@ def _groups_packed(fam, L, D, R, do_filter):
     return amplicon.groups_from_records(recs, [nm for nm, _, _ in fam], L, D, R)
 
 
-def _groups_wide(fam, L, D, R, do_filter, slots=True):
+def _groups_wide(fam, L, D, R, do_filter, slots=True, ordered=False):
     from krisp_amd import _native
     from krisp_amd import krisp_fasta as KF
     ids = list(range(len(fam)))
     with _native.Engine() as eng:
         eng.set_option(_native.OPT_WIDE_SLOTS, 1 if slots else 0)
+        eng.set_option(_native.OPT_WIDE_ORDERED, 1 if ordered else 0)
         eng.set_params_wide(L, D, R, max_bases=max(len(t) for _, _, t in fam))
         for i, (_, _, t) in enumerate(fam):
             eng.upload(i, t)
@@ -214,8 +215,11 @@ def test_wide_run_at_scale_properties():
     L, D, R = 30, 40, 30
     fam = synth.family(12, 2, 2, 20_000_000, records=16, mu=0.002, snp_every=5000)
     g1, info = _groups_wide(fam, L, D, R, True)
-    g2, info2 = _groups_wide(fam, L, D, R, True, slots=False)      # (dictionary look-ups through index + sorted keys)
-    assert info["slot_bits"][0] > 0 and info["slot_bits"][3] > 0 and info["slot_bits"][6] > 0 and not any(info2["slot_bits"])
+    g2, info2 = _groups_wide(fam, L, D, R, True, slots=False, ordered=True)      # (order-preserving ranks through index + sorted keys)
+    g3, info3 = _groups_wide(fam, L, D, R, True, ordered=True)                   # (... through slot tables)
+    assert info["slot_bits"][0] == 255 and info["slot_bits"][3] == 255      # (minimizer buckets for the 30-base flanks)
+    assert info["slot_bits"][6] > 0 and info3["slot_bits"][0] > 0 and info3["slot_bits"][3] > 0 and not any(info2["slot_bits"])
+    assert amplicon.merged_lines(g3) == amplicon.merged_lines(g1)
     l1 = amplicon.merged_lines(g1)
     assert l1 == amplicon.merged_lines(g2) and len(g1) > 100
     names = {nm for nm, _, _ in fam}

@@ -12,13 +12,15 @@ __device__ __forceinline__ u64 mix(u64 x) {
     return x;
 }
 // MODE 0: 8 bytes per look-up; 1: 64 bytes (4 x 16) of one aligned 64-byte slot; 2: 8 bytes, then a DEPENDENT
-// second 8-byte read at a place derived from the first (index + keys); 3: 32 bytes (2 x 16)
+// second 8-byte read at a place derived from the first (index + keys); 3: 32 bytes (2 x 16);
+// 4: 32 bytes, runs of 8 consecutive lanes read the SAME record (neighbouring windows that share a minimizer);
+// 5: as 4 with a dependent second 32-byte read shared by the same 8 lanes (bucket index, then bucket)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rand(const uint4* __restrict__ t, u64 nslots, u32 per, u32* out) {
     const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
     u32 acc = 0;
     for (u32 it = 0; it < per; it++) {
-        const u64 h = mix(tid * 0x9E3779B97F4A7C15ull + it);
+        const u64 h = mix((MODE >= 4 ? tid >> 3 : tid) * 0x9E3779B97F4A7C15ull + it);
         const u64 s = h & (nslots - 1);          // (nslots is a power of two: no 64-bit division in the loop)
         const uint4* p = t + 4 * s;
         if (MODE == 0) {
@@ -26,9 +28,14 @@ __global__ __launch_bounds__(256) void k_rand(const uint4* __restrict__ t, u64 n
         } else if (MODE == 1) {
             const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
             acc += a.x ^ b.y ^ c.z ^ d.w;
-        } else if (MODE == 3) {
+        } else if (MODE == 3 || MODE == 4) {
             const uint4 a = p[0], b = p[1];
             acc += a.x ^ b.y;
+        } else if (MODE == 5) {
+            const uint4 a = p[0];
+            const u64 s2 = mix(h + a.x) & (nslots - 1);
+            const uint4 c = t[4 * s2], d = t[4 * s2 + 1];
+            acc += c.x ^ d.y;
         } else {
             const u32 v = ((const u32*)p)[0];
             const u64 s2 = mix(h + v) & (nslots - 1);
@@ -50,10 +57,10 @@ int main() {
     CHECK(hipEventCreate(&b));
     const u32 grid = 256 * 32, per = 64;
     const double looks = (double)grid * 256 * per;
-    for (u64 gb4 : {1ull, 4ull, 16ull, 64ull, 128ull, 256ull}) {     // quarters of a GiB
+    for (u64 gb4 : {1ull, 16ull, 64ull, 128ull}) {     // quarters of a GiB
         const u64 bytes = gb4 << 28, nslots = bytes / 64;
         printf("footprint %6.2f GiB:", bytes / double(1ull << 30));
-        for (int mode = 0; mode < 4; mode++) {
+        for (int mode = 0; mode < 6; mode++) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; rep++) {
                 CHECK(hipEventRecord(a));
@@ -61,7 +68,9 @@ int main() {
                 case 0: hipLaunchKernelGGL(k_rand<0>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
                 case 1: hipLaunchKernelGGL(k_rand<1>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
                 case 2: hipLaunchKernelGGL(k_rand<2>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
-                default: hipLaunchKernelGGL(k_rand<3>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
+                case 3: hipLaunchKernelGGL(k_rand<3>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
+                case 4: hipLaunchKernelGGL(k_rand<4>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
+                default: hipLaunchKernelGGL(k_rand<5>, dim3(grid), dim3(256), 0, 0, t, nslots, per, out); break;
                 }
                 CHECK(hipEventRecord(b));
                 CHECK(hipEventSynchronize(b));
@@ -69,7 +78,7 @@ int main() {
                 CHECK(hipEventElapsedTime(&ms, a, b));
                 if (ms < best) best = ms;
             }
-            printf("  %s %6.2f G/s", mode == 0 ? "8B" : mode == 1 ? "64B" : mode == 2 ? "8B+dep8B" : "32B", looks / best / 1e6);
+            printf("  %s %6.2f G/s", mode == 0 ? "8B" : mode == 1 ? "64B" : mode == 2 ? "8B+dep8B" : mode == 3 ? "32B" : mode == 4 ? "32B/8lanes" : "32B+dep32B/8lanes", looks / best / 1e6);
         }
         printf("\n");
         fflush(stdout);
