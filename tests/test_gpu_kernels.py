@@ -195,6 +195,10 @@ def test_options_are_checked(N, monkeypatch):
         with pytest.raises(N.KrispHipError):
             e.set_option(N.OPT_ABLATE, 64)
         with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_WIDE_SLOTS, 2)
+        with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_WIDE_ORDERED, -1)
+        with pytest.raises(N.KrispHipError):
             e.set_option(99, 0)
         text = _rand_text(5, 100_000, b"ACGT", records=2)
         e.set_params(25, 1, 2, max_bases=len(text))
