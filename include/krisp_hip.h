@@ -183,7 +183,10 @@ int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
  * uploaded text, strand = 1 when the member is the reverse complement of that window */
 typedef struct { uint32_t cand, genome, pos, strand; } kr_wide_hit;
 int     kr_set_params_wide(kr_ctx*, int L, int D, int R, int softmask_mode, size_t max_bases);
-/* genomes: kr_genome_upload.  Returns the number of hits (grouped by cand, ascending). */
+/* genomes: kr_genome_upload.  Returns the number of hits (grouped by cand, ascending).
+ * With a communicator (kr_comm_init*) the call is collective: every rank passes ITS genomes (ids unique over
+ * the ranks), the flank spectra, the group list and the kept groups' mask words are exchanged inside;
+ * rank 0 ends with the hits of all ranks (genome = the caller's id, not an index; no order), the others with their own. */
 int64_t kr_wide_run(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup, int apply_filter);
 enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L > 32: their rank:rank combinations) */
        KR_WIDE_DICT_RIGHT = 1,  /* u64: rights present in all genomes, sorted (R > 32: likewise) */

@@ -389,8 +389,12 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
     from . import distributed as D
     k = amplicon_len
     Le, De, Re = codec.effective_geometry(L, k - L - R, R)
-    _check_geometry(Le, De, Re)
     do_filter = k > L + R
+    wide = Le + De + Re > 32 or De > 16            # amplicons longer than one key: kr_wide_run, collective inside
+    if wide and not (do_filter and De == 0):
+        _check_wide(Le, De, Re)
+    elif not wide:
+        _check_geometry(Le, De, Re)
     # interleave ingroup / outgroup files so that a round-robin shard holds both kinds
     ing, outg = list(ingroup_files), list(outgroup_files)
     order = []
@@ -439,6 +443,36 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         quirk_all_fail = do_filter and De == 0
         filt = do_filter and not quirk_all_fail
 
+        if wide:
+            if quirk_all_fail:
+                eng.comm_barrier()
+                stats.update(device_s=0.0, kmers=0, candidates=0, records=0)
+                return ([] if rank == 0 else None), stats
+
+            def wide_part():
+                # the spectra lists, the group list and the kept groups' masks are exchanged inside kr_wide_run
+                # (the same calls in the same order on every rank); hits name genomes by their global number
+                eng.set_params_wide(Le, De, Re, omit_soft=omit_soft, max_bases=int(kinds[2]))
+                for g, (bases, _, _) in zip(mine, loaded):
+                    eng.upload(g, bases)
+                nh = eng.wide_run(mine, [labels[g] in ingroup_labels for g in mine], apply_filter=do_filter)
+                return nh, int(sum(eng.wide_fetch(_native.WIDE_COUNTS).tolist())), len(eng.wide_fetch(_native.WIDE_GROUPS))
+
+            nh, counts, ngroups = together(wide_part)
+            hits = eng.wide_fetch(_native.WIDE_HITS) if (rank == 0 and nh) else np.empty(0, dtype=_native.WIDE_HIT)
+            eng.comm_barrier()
+            stats.update(device_s=time.time() - t1, kmers=counts, candidates=ngroups, records=int(len(hits)))
+            if rank != 0:
+                return None, stats
+            # rank 0 cuts the windows' text: its own genomes are in memory, the others' files are read here
+            texts = [None] * len(order)
+            for g, (bases, _, _) in zip(mine, loaded):
+                texts[g] = bases
+            for g in sorted(set(hits["genome"].tolist())):
+                if texts[g] is None:
+                    texts[g] = fasta.ingest(order[g], k, omit_soft)[0]
+            return _groups_from_hits(hits, texts, labels, Le, De, Re), stats
+
         def device_part():
             eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=int(kinds[2]))
             for g, (bases, _, _) in zip(mine, loaded):
@@ -470,9 +504,10 @@ def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, 
     every rank can prune with the monotone filter), each rank sorts and intersects its own, the
     candidate lists are tree-reduced between the GPUs (kr_cands_reduce: RCCL, device to device),
     the survivors broadcast, every rank collects its genomes' records and rank 0 gathers them.
-    Returns (groups, stats) on rank 0 and (None, stats) elsewhere.  The one-key path only
-    (k <= 32, D <= 16), no IUPAC letters, no RNA: those need look-ups across all genomes and stay
-    on one GPU.  A rank that fails (missing file, illegal character, out of memory) makes every
+    Returns (groups, stats) on rank 0 and (None, stats) elsewhere.  Amplicons longer than one key
+    take kr_wide_run, which exchanges the flank spectra, the group list and the kept groups' masks
+    between the ranks itself.  No IUPAC letters, no RNA: those need look-ups across all genomes
+    and stay on one GPU.  A rank that fails (missing file, illegal character, out of memory) makes every
     rank raise before the next collective: nobody is left waiting."""
     from . import distributed as D
     rank, local_rank, world = D.env_rank_world()

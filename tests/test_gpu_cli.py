@@ -364,11 +364,75 @@ def test_ranks_sharing_the_gpu_run_the_library_exchange(world, tmp_path):
     assert "GPU_DIST_OK" in outs[0], outs[0]
 
 
+WIDE_DIST_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["KR_ROOT"])
+from krisp_amd import _native, amplicon, distributed as D, synth
+from krisp_amd import krisp_fasta as KF
+
+L, Dg, R = int(os.environ["KR_L"]), int(os.environ["KR_D"]), int(os.environ["KR_R"])
+filt = os.environ["KR_FILTER"] == "1"
+rank, _, world = D.env_rank_world()
+fam = synth.family(21, 3, 3, 1_500_000, records=5, mu=0.004, snp_every=2500, n_frac=0.001, lower_frac=0.01)
+names = [nm for nm, _, _ in fam]
+texts = [t for _, _, t in fam]
+mine = D.shard(list(range(len(fam))), rank, world)
+eng = _native.Engine(device=0)
+D.connect(eng, rank, world, transport="dir", path=os.environ["KR_COMM"])
+eng.set_params_wide(L, Dg, R, max_bases=max(len(t) for t in texts))
+for g in mine:
+    eng.upload(g, texts[g])
+nh = eng.wide_run(mine, [fam[g][1] for g in mine], apply_filter=filt)
+if rank == 0:
+    hits = eng.wide_fetch(_native.WIDE_HITS)
+    got = amplicon.merged_lines(KF._groups_from_hits(hits, texts, names, L, Dg, R))
+    with _native.Engine(device=0) as one:            # the same genomes on one GPU, no communicator
+        one.set_params_wide(L, Dg, R, max_bases=max(len(t) for t in texts))
+        for g, t in enumerate(texts):
+            one.upload(g, t)
+        n1 = one.wide_run(list(range(len(fam))), [f for _, f, _ in fam], apply_filter=filt)
+        want = amplicon.merged_lines(KF._groups_from_hits(one.wide_fetch(_native.WIDE_HITS), texts, names, L, Dg, R))
+    assert nh == n1 > 0, (nh, n1)
+    assert got == want
+    print("WIDE_DIST_OK", nh, len(got))
+eng.comm_barrier()
+eng.close()
+'''
+
+
+@pytest.mark.parametrize("world,geo,filt", [(2, (30, 40, 30), True), (3, (30, 40, 30), True), (3, (40, 20, 36), True),
+                                            (2, (20, 30, 20), False), (5, (32, 60, 32), True)])
+def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
+    """kr_wide_run with a communicator: 6 genomes of 1.5 Mbp sharded over `world` ranks (sharing cuda:0,
+    file transport): the flank spectra and the group list are intersected over the ranks by the tree
+    reduction (lists of millions of entries), every rank locates its own windows, the kept groups'
+    mask words travel one 16-column word per round, rank 0 filters on the complete masks and gathers the
+    hits -- the same groups, members and counts as all six genomes on one GPU"""
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(WIDE_DIST_WORKER)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), KR_ROOT=ROOT,
+                   KR_COMM=str(tmp_path / "comm"), KR_L=str(geo[0]), KR_D=str(geo[1]), KR_R=str(geo[2]),
+                   KR_FILTER="1" if filt else "0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "WIDE_DIST_OK" in outs[0], outs[0]
+
+
+@pytest.mark.parametrize("name", ["c1_25_1_2", "c1_30_40_30", "rand9_20_10_20", "c1_30_0_30_all_ingroup", "c1_32_60_32"])
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
-def test_krisp_fasta_over_several_devices_from_one_process(devices, tmp_path):
+def test_krisp_fasta_over_several_devices_from_one_process(devices, name, tmp_path):
     """--devices: a thread per listed device inside one process (here the same GPU listed again: the
-    exchange then goes through files) -- the reference's output, byte for byte"""
-    case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
+    exchange then goes through files) -- the reference's output, byte for byte.  The cases with
+    amplicons longer than one key run kr_wide_run over the ranks: the flank spectra, the group list
+    and the kept groups' mask words are exchanged inside the library."""
+    case = [c for c in FC if c["name"] == name][0]
     paths = _paths(case, tmp_path)
     aln = str(tmp_path / "a.txt")
     csv = _run_main([paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
@@ -572,19 +636,19 @@ def test_kstream_command_line_as_documented(tmp_path):
     assert out2.returncode == 0 and outp.read_bytes() == out.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_krisp_fasta_command_line_over_several_ranks(world, tmp_path):
+@pytest.mark.parametrize("world,name", [(2, "c1_25_1_2"), (3, "c1_25_1_2"), (2, "c1_30_40_30"), (3, "rand9_20_10_20")])
+def test_krisp_fasta_command_line_over_several_ranks(world, name, tmp_path):
     """python -m torch.distributed.run ... -m krisp_amd.krisp_fasta: genomes sharded over the ranks
     (here sharing the one GPU: the file transport of the library's exchange), candidate tree reduction,
     records gathered to rank 0 -- the output is the reference's, byte for byte"""
     import subprocess
     import sys
-    case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
+    case = [c for c in FC if c["name"] == name][0]
     paths = _paths(case, tmp_path)
     aln = str(tmp_path / "a.txt")
     csvp = str(tmp_path / "o.csv")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29600 + world), "-m", "krisp_amd.krisp_fasta"]
+           "--master-addr", "127.0.0.1", "--master-port", str(29600 + world + 10 * (len(name) % 7)), "-m", "krisp_amd.krisp_fasta"]
     cmd += [paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
     cmd += case["main_args"] + ["--out_align", aln, "--out_csv", csvp]
     env = dict(os.environ, KRISP_COMM_TRANSPORT="dir", KRISP_COMM_FILE=str(tmp_path / "comm"))
