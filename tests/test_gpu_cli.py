@@ -425,6 +425,28 @@ def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
     assert "WIDE_DIST_OK" in outs[0], outs[0]
 
 
+def test_wide_run_over_several_ranks_stops_together_when_one_rank_fails(tmp_path):
+    """kr_wide_run with a communicator when ONE rank runs out of its memory budget in the middle: that rank
+    returns its own error, the others return promptly ("another rank failed") instead of waiting in the
+    next exchange"""
+    import subprocess
+    import sys
+    worker = WIDE_DIST_WORKER.replace("eng = _native.Engine(device=0)",
+                                      "eng = _native.Engine(device=0, hbm_budget=(60 << 20) if rank == 1 else 0)")
+    script = tmp_path / "w.py"
+    script.write_text(worker)
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), KR_ROOT=ROOT,
+                   KR_COMM=str(tmp_path / "comm"), KR_L="30", KR_D="40", KR_R="30", KR_FILTER="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode != 0 for p in procs), outs
+    assert "hbm budget exceeded" in outs[1], outs[1]
+    assert "another rank failed" in outs[0] and "another rank failed" in outs[2], outs
+
+
 @pytest.mark.parametrize("name", ["c1_25_1_2", "c1_30_40_30", "rand9_20_10_20", "c1_30_0_30_all_ingroup", "c1_32_60_32"])
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
 def test_krisp_fasta_over_several_devices_from_one_process(devices, name, tmp_path):
