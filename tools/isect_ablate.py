@@ -1,4 +1,6 @@
-"""Where k_intersect's time goes: python tools/isect_ablate.py  (4 x 50 Mbp, 25/1/2)"""
+"""Where k_intersect's time goes (4 x 50 Mbp, 25/1/2).  The ablation switches exist only in a -DKR_ABLATE build:
+    bash tools/ab_build.sh ablate -DKR_ABLATE
+    KRISP_HIP_LIB=$PWD/krisp_amd/variants/ablate.so python tools/isect_ablate.py"""
 import sys
 
 import numpy as np

@@ -163,6 +163,20 @@ int main() {
                 printf("  GB/s\n");
             }
     };
+    // the same scatter on smaller arrays: does the 256 MB memory-side cache (which merges partial lines before
+    // they reach DRAM) lift the rate of unaligned runs?  512-byte runs, 8-byte stores, read + write footprint 2 x bytes
+    for (u64 n16 : {50000000ull, 12500000ull, 6250000ull, 3125000ull, 1562500ull}) {
+        constexpr int RUN16 = 32;
+        const u32 ntiles = (u32)(n16 / (256 * RUN16));
+        const u64 bucket16 = (u64)ntiles * RUN16;
+        printf("array %6.1f MB, runs 512 B:", n16 * 16 / 1e6);
+        for (u32 shift8 : {0u, 1u}) {
+            double t = timeit([&] { hipLaunchKernelGGL((k_scatter<RUN16, 1>), dim3(256), dim3(1024), 0, 0, a, b, ntiles, bucket16, shift8, 0u); }, 20);
+            printf("  +%u B: %4.0f", shift8 * 8, 2.0 * (u64)ntiles * 256 * RUN16 * 16 / t / 1e6);
+        }
+        double tc = timeit([&] { hipLaunchKernelGGL(k_copy<1>, dim3(1024), dim3(256), 0, 0, a, b, n16); }, 20);
+        printf("   copy %4.0f GB/s\n", 2.0 * n16 * 16 / tc / 1e6);
+    }
     run(std::integral_constant<int, 8>{}, 128);
     run(std::integral_constant<int, 16>{}, 256);
     run(std::integral_constant<int, 32>{}, 512);
