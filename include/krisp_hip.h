@@ -195,7 +195,9 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
        KR_WIDE_COUNTS = 4,      /* u64 per genome of the last run: its k-mer records (2 x valid windows) */
        KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
                                    one-sector slot table in the last run, 0 = looked up through index + sorted keys,
-                                   255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0) */
+                                   255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0), 254 = not built: with L = R the
+                                   rights present in every genome are the reverse complements of the lefts, and a right
+                                   takes the number of that left */
 int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* returns #elements; out == NULL: size query */
 
 /* Host-side ingest (no GPU involved): the text of a FASTA / sequence-per-line file -> the

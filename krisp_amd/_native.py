@@ -393,6 +393,10 @@ class Engine:
         return self._check(self.lib.kr_wide_run(self.ctx, _ptr(ids), len(ids), _ptr(flags),
                                                 1 if apply_filter else 0), "kr_wide_run")
 
+    def wide_count(self, what):
+        """number of entries kr_wide_fetch(what) would return"""
+        return self._check(self.lib.kr_wide_fetch(self.ctx, what, None, 0), "kr_wide_fetch")
+
     def wide_fetch(self, what):
         n = self._check(self.lib.kr_wide_fetch(self.ctx, what, None, 0), "kr_wide_fetch")
         out = np.empty(max(n, 1), dtype=WIDE_HIT if what == WIDE_HITS else np.uint64)

@@ -147,6 +147,8 @@ def test_random_wide_geometries_match_the_text_oracle(seed, tmp_path, monkeypatc
         monkeypatch.setenv("KR_WIDE_SLOTS", "0")      # dictionaries as index + sorted keys only (no slot tables)
     if seed % 2 == 1:
         monkeypatch.setenv("KR_WIDE_ORDERED", "1")    # order-preserving ranks instead of minimizer-bucket numbers
+    if seed % 6 == 0:
+        monkeypatch.setenv("KR_WIDE_SHARE", "0")      # L == R: build the right spectrum although it mirrors the left one
     n_in, n_out = rng.randint(1, 3), rng.randint(0, 2)
     if n_in + n_out == 1:
         n_out = 1

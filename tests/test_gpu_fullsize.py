@@ -141,7 +141,7 @@ def test_c3_eight_half_gbp_genomes_long_amplicons():
         eng.sync()
         t3 = time.time()
         hits = eng.wide_fetch(_native.WIDE_HITS)
-        sizes = [len(eng.wide_fetch(w)) for w in (0, 1, 2)]
+        sizes = [eng.wide_count(w) for w in (0, 1, 2)]
     assert n == len(hits) > 0
     groups = KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R)
     names = {nm for nm, _, _ in fam}
@@ -182,8 +182,8 @@ def _groups_wide(fam, L, D, R, do_filter, slots=True, ordered=False):
             eng.upload(i, t)
         n = eng.wide_run(ids, [f for _, f, _ in fam], apply_filter=do_filter)
         hits = eng.wide_fetch(_native.WIDE_HITS) if n else np.empty(0, dtype=_native.WIDE_HIT)
-        info = dict(nl=len(eng.wide_fetch(_native.WIDE_DICT_LEFT)), nr=len(eng.wide_fetch(_native.WIDE_DICT_RIGHT)),
-                    ng=len(eng.wide_fetch(_native.WIDE_GROUPS)), slot_bits=[int(x) for x in eng.wide_fetch(_native.WIDE_SLOT_BITS)])
+        info = dict(nl=eng.wide_count(_native.WIDE_DICT_LEFT), nr=eng.wide_count(_native.WIDE_DICT_RIGHT),
+                    ng=eng.wide_count(_native.WIDE_GROUPS), slot_bits=[int(x) for x in eng.wide_fetch(_native.WIDE_SLOT_BITS)])
     return KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R), info
 
 
@@ -217,7 +217,7 @@ def test_wide_run_at_scale_properties():
     g1, info = _groups_wide(fam, L, D, R, True)
     g2, info2 = _groups_wide(fam, L, D, R, True, slots=False, ordered=True)      # (order-preserving ranks through index + sorted keys)
     g3, info3 = _groups_wide(fam, L, D, R, True, ordered=True)                   # (... through slot tables)
-    assert info["slot_bits"][0] == 255 and info["slot_bits"][3] == 255      # (minimizer buckets for the 30-base flanks)
+    assert info["slot_bits"][0] == 255 and info["slot_bits"][3] == 254      # (minimizer buckets for the 30-base lefts; the rights mirror them)
     assert info["slot_bits"][6] > 0 and info3["slot_bits"][0] > 0 and info3["slot_bits"][3] > 0 and not any(info2["slot_bits"])
     assert amplicon.merged_lines(g3) == amplicon.merged_lines(g1)
     l1 = amplicon.merged_lines(g1)

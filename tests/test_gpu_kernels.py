@@ -357,6 +357,41 @@ def test_more_genomes_than_one_intersect_call_takes(N, K):
     assert amplicon.merged_lines(wide) == amplicon.merged_lines(packed)
 
 
+@pytest.mark.parametrize("geo", [(12, 30, 12), (30, 8, 30), (32, 20, 32), (40, 12, 40)])
+def test_wide_right_flank_through_the_left_dictionary(N, geo, monkeypatch):
+    """L == R: the rights present in every genome are the reverse complements of the lefts, so kr_wide_run
+    builds one spectrum and numbers a right by that left (two look-ups per window start).  Against the same
+    run with both spectra built (KR_WIDE_SHARE=0): the same hits; the right dictionary made on request (flanks
+    of one key) equals the one that run builds."""
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    L, D, R = geo
+    fam = _family(91, 4, 300_000)
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+    texts, names = [t for _, _, t in fam], [nm for nm, _, _ in fam]
+
+    def run(share):
+        monkeypatch.setenv("KR_WIDE_SHARE", "1" if share else "0")
+        with N.Engine() as e:
+            e.set_params_wide(L, D, R, max_bases=max(len(t) for t in texts))
+            for i, t in enumerate(texts):
+                e.upload(i, t)
+            n = e.wide_run(ids, flags, apply_filter=False)
+            bits = [int(x) for x in e.wide_fetch(N.WIDE_SLOT_BITS)]
+            right = e.wide_fetch(N.WIDE_DICT_RIGHT) if L <= 32 else None
+            return n, bits, right, amplicon.merged_lines(KF._groups_from_hits(e.wide_fetch(N.WIDE_HITS), texts, names, L, D, R)), \
+                e.wide_count(N.WIDE_DICT_RIGHT), e.wide_count(N.WIDE_GROUPS)
+
+    n1, bits1, right1, lines1, nr1, ng1 = run(True)
+    n0, bits0, right0, lines0, nr0, ng0 = run(False)
+    assert bits1[3] == 254 and bits0[3] != 254
+    assert n1 == n0 > 0 and lines1 == lines0
+    assert nr1 == nr0 and ng1 == ng0
+    if right1 is not None:
+        assert np.array_equal(right1, right0)
+
+
 def test_stage_timers_and_medium_size(N, K):
     fam = _family(77, 4, 1_000_000)
     flags = [f for _, f, _ in fam]

@@ -36,7 +36,7 @@ def main():
             n = eng.wide_run(ids, flags, apply_filter=True)
             eng.sync()
             dt = time.time() - t0
-            sizes = [len(eng.wide_fetch(w)) for w in (0, 1, 2)]
+            sizes = [eng.wide_count(w) for w in (0, 1, 2)]
             windows = 2 * sum(len(t) for _, _, t in fam)
             print(f"run {rep}: {dt:.3f} s, {windows / dt / 1e9:.2f} G windows/s, hits {n}, dictL {sizes[0]}, "
                   f"dictR {sizes[1]}, groups {sizes[2]}", flush=True)

@@ -24,7 +24,7 @@ def main():
             n = eng.wide_run(ids, [f for _, f, _ in fam], apply_filter=True)
             eng.sync()
             dt = time.time() - t0
-            info = [len(eng.wide_fetch(w)) for w in (0, 1, 2)]
+            info = [eng.wide_count(w) for w in (0, 1, 2)]
             print(f"run {rep}: {dt * 1e3:.1f} ms, hits {n}, dictL {info[0]}, dictR {info[1]}, groups {info[2]}, "
                   f"{2 * sum(len(t) for _, _, t in fam) / dt / 1e9:.2f} G windows/s", flush=True)
             print("   ", {k: (round(v[0], 1), v[1]) for k, v in eng.stage_times().items() if v[1]}, flush=True)
