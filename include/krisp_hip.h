@@ -193,6 +193,10 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
        KR_WIDE_GROUPS = 2,      /* u64: composite keys of the groups present in all genomes (before the filter) */
        KR_WIDE_HITS = 3,        /* kr_wide_hit */
        KR_WIDE_COUNTS = 4,      /* u64 per genome of the last run: its k-mer records (2 x valid windows) */
+       KR_WIDE_NGROUPS = 6,     /* u64 x 1: the (left,right) groups present in all genomes (before the filter).  With L = R
+                                   (and KR_OPT_WIDE_ORDERED = 0) KR_WIDE_GROUPS lists one group of every mirror pair
+                                   (a:b) / (b:a) only -- the two are decided alike -- and a hit of the unlisted one
+                                   carries the listed one's number with bit 31 set */
        KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
                                    one-sector slot table in the last run, 0 = looked up through index + sorted keys,
                                    255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0), 254 = not built: with L = R the

@@ -336,7 +336,7 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
                 eng.upload(i, t)
             nhits = eng.wide_run(ids, flags, apply_filter=do_filter)
             hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
-            ngroups = eng.wide_count(_native.WIDE_GROUPS)
+            ngroups = int(eng.wide_fetch(_native.WIDE_NGROUPS)[0])
             counts = eng.wide_fetch(_native.WIDE_COUNTS).tolist()
             if verbose:
                 for f, cnt in zip(files, counts):
@@ -456,7 +456,7 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
                 for g, (bases, _, _) in zip(mine, loaded):
                     eng.upload(g, bases)
                 nh = eng.wide_run(mine, [labels[g] in ingroup_labels for g in mine], apply_filter=do_filter)
-                return nh, int(sum(eng.wide_fetch(_native.WIDE_COUNTS).tolist())), eng.wide_count(_native.WIDE_GROUPS)
+                return nh, int(sum(eng.wide_fetch(_native.WIDE_COUNTS).tolist())), int(eng.wide_fetch(_native.WIDE_NGROUPS)[0])
 
             nh, counts, ngroups = together(wide_part)
             hits = eng.wide_fetch(_native.WIDE_HITS) if (rank == 0 and nh) else np.empty(0, dtype=_native.WIDE_HIT)

@@ -183,7 +183,7 @@ def _groups_wide(fam, L, D, R, do_filter, slots=True, ordered=False):
         n = eng.wide_run(ids, [f for _, f, _ in fam], apply_filter=do_filter)
         hits = eng.wide_fetch(_native.WIDE_HITS) if n else np.empty(0, dtype=_native.WIDE_HIT)
         info = dict(nl=eng.wide_count(_native.WIDE_DICT_LEFT), nr=eng.wide_count(_native.WIDE_DICT_RIGHT),
-                    ng=eng.wide_count(_native.WIDE_GROUPS), slot_bits=[int(x) for x in eng.wide_fetch(_native.WIDE_SLOT_BITS)])
+                    ng=int(eng.wide_fetch(_native.WIDE_NGROUPS)[0]), slot_bits=[int(x) for x in eng.wide_fetch(_native.WIDE_SLOT_BITS)])
     return KF._groups_from_hits(hits, [t for _, _, t in fam], [nm for nm, _, _ in fam], L, D, R), info
 
 

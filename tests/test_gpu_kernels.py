@@ -381,7 +381,7 @@ def test_wide_right_flank_through_the_left_dictionary(N, geo, monkeypatch):
             bits = [int(x) for x in e.wide_fetch(N.WIDE_SLOT_BITS)]
             right = e.wide_fetch(N.WIDE_DICT_RIGHT) if L <= 32 else None
             return n, bits, right, amplicon.merged_lines(KF._groups_from_hits(e.wide_fetch(N.WIDE_HITS), texts, names, L, D, R)), \
-                e.wide_count(N.WIDE_DICT_RIGHT), e.wide_count(N.WIDE_GROUPS)
+                e.wide_count(N.WIDE_DICT_RIGHT), int(e.wide_fetch(N.WIDE_NGROUPS)[0])
 
     n1, bits1, right1, lines1, nr1, ng1 = run(True)
     n0, bits0, right0, lines0, nr0, ng0 = run(False)

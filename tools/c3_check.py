@@ -41,6 +41,7 @@ def main():
             print(f"run {rep}: {dt:.3f} s, {windows / dt / 1e9:.2f} G windows/s, hits {n}, dictL {sizes[0]}, "
                   f"dictR {sizes[1]}, groups {sizes[2]}", flush=True)
             print("   ", {k: (round(v[0], 1), v[1]) for k, v in eng.stage_times().items() if v[1]}, flush=True)
+            print("    (left,right) groups present in all genomes:", int(eng.wide_fetch(_native.WIDE_NGROUPS)[0]), flush=True)
             print("    slot bits (left 0..2, right 0..2, groups):", [int(x) for x in eng.wide_fetch(_native.WIDE_SLOT_BITS)], flush=True)
         hits = eng.wide_fetch(_native.WIDE_HITS)
     if os.environ.get("C3_NOCHECK") == "1":       # (timing experiments with variant libraries)
