@@ -639,7 +639,8 @@ def test_integration_md_binding_snippets_run():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "integration_check.py")], cwd=ROOT,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "records 10" in out.stdout and "wide hits 10 [0, 1]" in out.stdout
+    # (30/40/30: L = R, so the group list holds one group of the mirror pair; the other's hits carry bit 31)
+    assert "records 10" in out.stdout and "wide hits 10 [0, 2147483648]" in out.stdout
 
 
 def test_kstream_command_line_as_documented(tmp_path):
