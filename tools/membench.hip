@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_write(uint4* __restrict__ dst, u64 n16)
 // cursors fall on any 8-byte boundary); W8 = 1: 8-byte stores (one key per lane, as the sort
 // kernels store), 0: 16-byte stores; blocked = 1: a workgroup takes CONSECUTIVE tiles (adjacent
 // runs of a bucket then come from the same CU, one after the other), 0: tiles strided over the grid.
-template <int RUN16, int W8>
+template <int RUN16, int W8, int NOREAD = 0>
 __global__ __launch_bounds__(1024) void k_scatter(const uint4* __restrict__ src, uint4* __restrict__ dst, u32 ntiles,
                                                   u64 bucket16, u32 shift8, u32 blocked) {
     constexpr u32 tile16 = 256 * RUN16;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint4* __restrict__ src,
         for (int i0 = 0; i0 < IT; i0 += UN) {
             uint4 v[UN];
 #pragma unroll
-            for (int q = 0; q < UN; q++) v[q] = s[(i0 + q) * 1024 + threadIdx.x];
+            for (int q = 0; q < UN; q++) v[q] = NOREAD ? make_uint4(t, i0 + q, threadIdx.x, 7) : s[(i0 + q) * 1024 + threadIdx.x];
             if (W8) {
                 // lane l of a wave stores key 2l and key 2l+1 of its 16 bytes in two 8-byte store
                 // instructions that each cover the wave's span with stride 8 (as `dst[p] = key`)
@@ -176,6 +176,18 @@ int main() {
         }
         double tc = timeit([&] { hipLaunchKernelGGL(k_copy<1>, dim3(1024), dim3(256), 0, 0, a, b, n16); }, 20);
         printf("   copy %4.0f GB/s\n", 2.0 * n16 * 16 / tc / 1e6);
+    }
+    // write-only scatter (pass 1 generates its keys): 256-byte runs, 8-byte stores, by alignment of the run starts
+    {
+        constexpr int RUN16 = 16;
+        const u32 ntiles = (u32)(N16 / (256 * RUN16));
+        const u64 bucket16 = (u64)ntiles * RUN16;
+        printf("write-only, runs 256 B, 8-B stores:");
+        for (u32 shift8 : {0u, 1u, 2u, 4u, 8u}) {
+            double t = timeit([&] { hipLaunchKernelGGL((k_scatter<RUN16, 1, 1>), dim3(512), dim3(1024), 0, 0, a, b, ntiles, bucket16, shift8, 0u); }, 5);
+            printf("  +%2u B: %4.0f", shift8 * 8, 1.0 * N16 * 16 / t / 1e6);
+        }
+        printf("  GB/s\n");
     }
     run(std::integral_constant<int, 8>{}, 128);
     run(std::integral_constant<int, 16>{}, 256);
