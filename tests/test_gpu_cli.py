@@ -565,6 +565,11 @@ def test_random_genomes_with_iupac_letters_match_the_text_oracle(seed, tmp_path)
     ("identical_genomes", [">a\n" + "ACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAGCATCGACTAGCTACGACTAGCGACGGCATCGA\n"] * 3, 2),
     ("empty_record_and_blank_lines", [">a\n\n>b\nACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAG\n\n  CATCGACTAGCTACGAC  \n", ">c\nACGTTGCAAGGCTTAACCGGATATCGCGTTAAGGCCTTAGACTAGCATCGACTAGCTACGAC\n"], 1),
     ("palindromic_repeat", [">a\n" + "ACGT" * 40 + "\n", ">b\n" + "ACGT" * 45 + "\n"], 1),
+    # a window whose right flank is the reverse complement of its left flank (5/30/5: ACGGT ... ACCGT): both strands
+    # of the window fall into ONE group, which mirrors itself (the canonical-key form of the L = R path, a = b)
+    ("self_mirror_window", [">a\nTTGACCATGCAAGT" + "ACGGT" + "GATTACAGATTACAGATTACAGATTACAGAT" + "ACCGT" + "CCATGGTTAAC\n",
+                            ">b\nTTGACCATGCAAGT" + "ACGGT" + "GATTACAGATTACAGATTACAGATTACAGAT" + "ACCGT" + "CCATGGTTAAC\n",
+                            ">c\nTTGACCATGCAAGT" + "ACGGT" + "GATTACAGATTCCAGATTACAGATTACAGAT" + "ACCGT" + "CCATGGTTAAC\n"], 2),
 ])
 def test_wide_path_edge_cases_match_the_text_oracle(name, texts, n_in, tmp_path):
     from krisp_amd import amplicon
