@@ -244,6 +244,9 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
        KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4 */
        KR_OPT_ABLATE = 4,            /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
        KR_OPT_WIDE_SLOTS = 5,        /* wide path: 1 (default) dictionaries also as one-sector slot tables, 0 index + sorted keys only */
+       KR_OPT_PLACE_TRIES = 7,       /* 1 (default) .. 16: candidate allocations of the pass-1 output buffer (>= 256 MB), each timed under
+                                        pass 1's write pattern, the fastest kept: physical placement moves pass 1 / pass 2 by up to 15 %
+                                        from one allocation to the next; worth its ~5 ms per candidate for contexts that sort many genomes */
        KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
                                         of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
                                         ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */

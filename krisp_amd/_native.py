@@ -23,7 +23,7 @@ WIDE_MAX_FLANK = 64
 COMM_ID_BYTES = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
-OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE, OPT_WIDE_SLOTS, OPT_WIDE_ORDERED = 1, 2, 3, 4, 5, 6
+OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE, OPT_WIDE_SLOTS, OPT_WIDE_ORDERED, OPT_PLACE_TRIES = 1, 2, 3, 4, 5, 6, 7
 ERR_KEY, ERR_HOST = -5, -6
 STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",

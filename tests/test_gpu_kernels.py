@@ -195,6 +195,8 @@ def test_options_are_checked(N, monkeypatch):
         with pytest.raises(N.KrispHipError):
             e.set_option(N.OPT_ABLATE, 64)
         with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_PLACE_TRIES, 0)
+        with pytest.raises(N.KrispHipError):
             e.set_option(N.OPT_WIDE_SLOTS, 2)
         with pytest.raises(N.KrispHipError):
             e.set_option(N.OPT_WIDE_ORDERED, -1)
@@ -390,6 +392,25 @@ def test_wide_right_flank_through_the_left_dictionary(N, geo, monkeypatch):
     assert nr1 == nr0 and ng1 == ng0
     if right1 is not None:
         assert np.array_equal(right1, right0)
+
+
+def test_placement_tries_change_nothing_but_time(N, K):
+    """KR_OPT_PLACE_TRIES: the pass-1 output buffer is chosen among several allocations (each timed under
+    pass 1's write pattern); the result is the same as with a plain allocation"""
+    fam = _family(55, 4, 40_000_000)            # (buffers of >= 256 MB: below that nothing is tried)
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+    got = []
+    for tries in (1, 3):
+        with N.Engine() as e:
+            e.set_option(N.OPT_PLACE_TRIES, tries)
+            e.set_params(25, 1, 2, max_bases=max(len(t) for _, _, t in fam))
+            for i, (_, _, t) in enumerate(fam):
+                e.add(i, t)
+            assert all(e.inversions(i) == 0 for i in ids)
+            n = e.intersect(ids, flags, apply_filter=True)
+            got.append((n, e.cands().tobytes(), e.collect(ids).tobytes()))
+    assert got[0][0] > 0 and got[0] == got[1]
 
 
 def test_stage_timers_and_medium_size(N, K):
