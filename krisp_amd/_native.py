@@ -24,6 +24,7 @@ COMM_ID_BYTES = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
 OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE, OPT_WIDE_SLOTS, OPT_WIDE_ORDERED, OPT_PLACE_TRIES = 1, 2, 3, 4, 5, 6, 7
+OPT_ISECT_KERNEL = 8
 ERR_KEY, ERR_HOST = -5, -6
 STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
@@ -94,6 +95,7 @@ SYMBOLS = [
     ("kr_debug_intersect", _c.c_double, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int]),
     ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
+    ("kr_debug_isect", _c.c_int, [_P, _P]),
 ]
 
 
@@ -244,7 +246,7 @@ class Engine:
 
     # ---- configuration
     def set_option(self, option, value):
-        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_WIDE_SLOTS); before set_params"""
+        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ISECT_KERNEL, OPT_WIDE_SLOTS); before set_params"""
         self._check(self.lib.kr_set_option(self.ctx, option, int(value)), "kr_set_option")
 
     def set_params(self, L, D, R, omit_soft=False, max_bases=0):
@@ -439,6 +441,11 @@ class Engine:
         self.lib.kr_debug_info(self.ctx, _ptr(o))
         return dict(b=int(o[0]), nbuckets=int(o[1]), T=int(o[2]), CAP=int(o[3]), nwg=int(o[4]),
                     overflow_segments=int(o[5]), fallback_launches=int(o[6]), nslices=int(o[7]))
+
+    def debug_isect(self):
+        o = np.zeros(4, dtype=np.int64)
+        self.lib.kr_debug_isect(self.ctx, _ptr(o))
+        return dict(chunk_kernel_items=int(o[0]), slices_redone=int(o[1]), threads=int(o[2]), buckets_per_item_log2=int(o[3]))
 
     def copy_gbps(self, nbytes=1 << 30, reps=10):
         v = self.lib.kr_debug_copy_gbps(self.ctx, nbytes, reps)

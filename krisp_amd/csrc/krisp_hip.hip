@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <cerrno>
 #include <map>
 #include <mutex>
@@ -33,6 +34,7 @@
 #include "k_sort.inc"        // pack, histograms, pass 0 / 1 / 2, chunk table, LDS sort, merge fallback
 #include "k_sort2.inc"       // pass 1 / pass 2 / LDS sort as persistent, software-pipelined kernels (buffer loads, counted waits)
 #include "k_intersect.inc"   // n-way intersection, candidate compaction, collection, list merge
+#include "k_intersect3.inc"  // the same intersection as a persistent, software-pipelined kernel (items of whole buckets)
 #include "k_wide.inc"        // wide path kernels, copy kernel
 
 #include "h_core.inc"        // context, buffers, parameters, upload, sort, finalize   (opens extern "C")

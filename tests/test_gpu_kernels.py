@@ -155,11 +155,13 @@ def test_sort_in_key_space_slices_vs_oracle(N, K, sb, n, L, D, R, omit):
     assert info["nslices"] == 4 ** min(sb, L)
 
 
-@pytest.mark.parametrize("sb,generic,fmt", [(1, 0, 0), (2, 0, 0), (0, 1, 0), (0, 0, 1), (2, 1, 1)])
+@pytest.mark.parametrize("sb,generic,fmt,kern", [(1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (2, 1, 1, 0),
+                                                 (0, 0, 0, 1), (1, 0, 1, 1)])
 @pytest.mark.parametrize("L,D,R,length,n", [(25, 1, 2, 200_000, 4), (12, 4, 12, 100_000, 3), (8, 1, 4, 20_000, 5)])
-def test_intersect_and_collect_under_every_option(N, K, sb, generic, fmt, L, D, R, length, n):
+def test_intersect_and_collect_under_every_option(N, K, sb, generic, fmt, kern, L, D, R, length, n):
     """the result-neutral options of kr_set_option (key-space slices, generic intersect sub-tiles,
-    narrow per-prefix state): candidates, masks and records equal the packed oracle's under each"""
+    narrow per-prefix state, the chunk kernel instead of the pipelined one): candidates, masks and
+    records equal the packed oracle's under each"""
     fam = _family(L + D + R + sb, n, length)
     flags = [f for _, f, _ in fam]
     want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
@@ -167,6 +169,7 @@ def test_intersect_and_collect_under_every_option(N, K, sb, generic, fmt, L, D, 
         e.set_option(N.OPT_SLICE_BASES, sb)
         e.set_option(N.OPT_GENERIC_INTERSECT, generic)
         e.set_option(N.OPT_ISECT_FORMAT, fmt)
+        e.set_option(N.OPT_ISECT_KERNEL, kern)
         e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
         assert e.debug_info()["nslices"] == 4 ** min(sb, L)
         for i, (_, _, t) in enumerate(fam):
@@ -325,6 +328,93 @@ def test_intersect_and_collect(N, K, L, D, R, length, n):
             assert np.array_equal(got["prefix"], want_f["prefix"])
             assert np.array_equal(got["in_mask"], want_f["in_mask"])
             assert np.array_equal(got["out_mask"], want_f["out_mask"])
+
+
+def _check_intersect(N, K, texts, flags, L, D, R, env=None):
+    """n-way intersect + collect of `texts` against the packed oracle, unfiltered and filtered"""
+    n = len(texts)
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
+    with N.Engine() as e:
+        e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
+        for i, t in enumerate(texts):
+            assert e.add(i, t) == len(want_keys[i])
+        for filt in (False, True):
+            want = K.intersect(want_keys, flags, L, D, R, apply_filter=filt)
+            assert e.intersect(list(range(n)), flags, apply_filter=filt) == len(want)
+            got = e.cands()
+            for f in ("prefix", "in_mask", "out_mask"):
+                assert np.array_equal(got[f], want[f]), (f, filt)
+            recs = e.collect(list(range(n)))
+            wrec = np.sort(K.collect(want_keys, want, L, D, R), order=["key", "genome"])
+            assert np.array_equal(recs, wrec)
+        return e.debug_isect(), e.debug_info()
+
+
+@pytest.mark.parametrize("length,threads,mlog", [(500_000, 320, 0), (600_000, 384, 0), (700_000, 448, 0), (800_000, 512, 0),
+                                                 (450_000, 512, 1), (3_000, None, None)])
+def test_pipelined_intersect_item_shapes(N, K, length, threads, mlog):
+    """k_intersect3 at every workgroup size the host picks (items of 4 T slots sized from the bucket
+    statistics: 256 .. 512 threads, one or several buckets per item), anchor = the shortest genome"""
+    from krisp_amd import synth
+    fam = synth.family(length % 97, 2, 1, length, records=3, mu=0.01, snp_every=1500)
+    texts = [t for _, _, t in fam]
+    texts[1] = texts[1][: len(texts[1]) - 37]            # the anchor (fewest keys) is not genome 0
+    info, _ = _check_intersect(N, K, texts, [f for _, f, _ in fam], 20, 2, 5)
+    assert (threads is None or info["threads"] == threads) and info["slices_redone"] == 0
+    if mlog is not None:
+        assert info["buckets_per_item_log2"] == mlog
+
+
+@pytest.mark.parametrize("L,D,R,n", [(20, 1, 6, 7), (11, 6, 10, 4), (9, 10, 9, 5), (12, 16, 4, 3), (16, 0, 16, 6), (10, 1, 3, 32)])
+def test_pipelined_intersect_formats_and_genome_counts(N, K, L, D, R, n):
+    """every per-prefix state format (D <= 4, <= 8, <= 16) and 3 .. 32 genomes per call"""
+    from krisp_amd import synth
+    fam = synth.family(L + n, (n + 1) // 2, n // 2, 120_000, records=2, mu=0.004, snp_every=700)
+    info, _ = _check_intersect(N, K, [t for _, _, t in fam], [f for _, f, _ in fam], L, D, R)
+    assert info["threads"] >= 256
+
+
+def test_pipelined_intersect_runs_of_equal_prefixes(N, K):
+    """genomes that hold every stretch twice, the copy with substitutions: runs of anchor keys with one
+    (left,right) prefix -- equal keys and keys that differ in the diagnostic columns only"""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 4, size=150_000)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    texts = []
+    for g in range(4):
+        a = base.copy()
+        m = rng.random(len(a)) < 0.004
+        a[m] = (a[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+        b2 = a.copy()
+        m = rng.random(len(a)) < 0.03
+        b2[m] = (b2[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+        texts.append(np.concatenate([acgt[a], [10], acgt[b2], [10], acgt[a[:40_000]]]).astype(np.uint8))
+    _check_intersect(N, K, texts, [1, 1, 0, 0], 8, 2, 3)
+    _check_intersect(N, K, texts, [1, 0, 1, 0], 13, 1, 2)
+
+
+def test_pipelined_intersect_oversized_items(N, K, monkeypatch):
+    """skew: satellites put more keys into some items than a workgroup has slots -- those items go to the
+    chunk kernel; with more of them than its list holds (KR_ISECT_OVF_CAP lowers it for the test) the
+    whole slice is redone by chunks.  Same candidates and records either way."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = rng.integers(0, 4, size=400_000)
+    unit = rng.integers(0, 4, size=37)
+    texts = []
+    for g in range(3):
+        a = base.copy()
+        m = rng.random(len(a)) < 0.005
+        a[m] = (a[m] + 1) % 4
+        sat = np.tile(unit, 4000 + 50 * g)
+        ms = rng.random(len(sat)) < 0.02
+        sat[ms] = (sat[ms] + 2) % 4
+        texts.append(np.concatenate([acgt[a[:200_000]], acgt[sat], acgt[a[200_000:]]]).astype(np.uint8))
+    info, _ = _check_intersect(N, K, texts, [1, 0, 0], 14, 1, 6)
+    assert info["chunk_kernel_items"] > 0 and info["slices_redone"] == 0
+    monkeypatch.setenv("KR_ISECT_OVF_CAP", "2")
+    info, _ = _check_intersect(N, K, texts, [1, 0, 0], 14, 1, 6)
+    assert info["slices_redone"] > 0
 
 
 def test_more_genomes_than_one_intersect_call_takes(N, K):
