@@ -169,8 +169,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--place-tries", type=int, default=8,
-                    help="KR_OPT_PLACE_TRIES: candidate allocations of the pass-1 output buffer, the fastest is kept")
+    ap.add_argument("--place-tries", type=int, default=None,
+                    help="KR_OPT_PLACE_TRIES: candidate allocations of the pass-1 output buffer, the fastest is kept "
+                         "(default: the library's own default, 8 -- what the command line runs with, too)")
     ap.add_argument("--length", type=int, default=50_000_000, help="bases per genome (C2: 50 Mbp)")
     ap.add_argument("--per-gpu", type=int, default=4, help="genomes per GPU")
     ap.add_argument("--ldr", type=int, nargs=3, default=[25, 1, 2])
@@ -206,10 +207,11 @@ def main():
     comm = world > 1 or args.force_comm
     if comm:
         D.connect(eng, rank, world, transport=args.transport)
-    # a context that sorts the same buffers step after step: let the library choose among a few allocations of its
-    # pass-1 output buffer (physical placement moves pass 1 / pass 2 by up to 15 %; KR_PLACE_TRIES overrides)
-    if "KR_PLACE_TRIES" not in os.environ:
+    # (the library chooses among 8 allocations of its pass-1 output buffer by itself -- physical placement moves
+    # pass 1 / pass 2 by up to 15 % --: bench and command line run the same code; --place-tries is an A/B switch)
+    if args.place_tries is not None:
         eng.set_option(_native.OPT_PLACE_TRIES, args.place_tries)
+    place_tries = args.place_tries if args.place_tries is not None else int(os.environ.get("KR_PLACE_TRIES", "8"))
     eng.set_params(L, Dg, R, omit_soft=False, max_bases=max(len(t) for _, _, t in genomes))
     ids = []
     for g, ing, text in genomes:
@@ -227,15 +229,7 @@ def main():
     nrec = [0]
 
     def step():
-        for g in ids:
-            eng.sort(g)
-        n = eng.intersect(ids, flags, apply_filter=True)     # (N > 1: safe local pruning, the predicate is monotone)
-        if world > 1:
-            n = eng.cands_reduce(apply_filter=True)
-            if not args.no_collect:
-                eng.cands_bcast()
-        if not args.no_collect:
-            nrec[0] = eng.collect(ids, fetch=False)          # the records stay in HBM
+        n, nrec[0] = D.sharded_step(eng, ids, flags, world, apply_filter=True, collect=not args.no_collect)
         return n
 
     for _ in range(args.warmup):
@@ -332,6 +326,7 @@ def main():
                        "step": "sort every genome + n-way intersect + filter"
                                + ("" if args.no_collect else " + collect the candidate records (resident in HBM)"),
                        "kmers_per_step": kmers_total, "candidates": int(ncand), "records": int(records_total),
+                       "place_tries": place_tries,
                        "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else
                                       f" + tree-reduce of candidates ({args.transport})")},
             "roofline": roof,

@@ -244,7 +244,7 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
        KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4 */
        KR_OPT_ABLATE = 4,            /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
        KR_OPT_WIDE_SLOTS = 5,        /* wide path: 1 (default) dictionaries also as one-sector slot tables, 0 index + sorted keys only */
-       KR_OPT_PLACE_TRIES = 7,       /* 1 (default) .. 16: candidate allocations of the pass-1 output buffer (>= 256 MB), each timed under
+       KR_OPT_PLACE_TRIES = 7,       /* 1 .. 16 (default 8): candidate allocations of the pass-1 output buffer (>= 256 MB), each timed under
                                         pass 1's write pattern, the fastest kept: physical placement moves pass 1 / pass 2 by up to 15 %
                                         from one allocation to the next; worth its ~5 ms per candidate for contexts that sort many genomes */
        KR_OPT_ISECT_KERNEL = 8,      /* 0 (default) the persistent, pipelined intersect kernel over items of whole buckets wherever a
@@ -287,6 +287,9 @@ double  kr_debug_copy_gbps(kr_ctx*, size_t bytes, int reps);
 /* the pipelined intersect kernel: items that went to the chunk kernel (oversized), slices redone by chunks,
  * threads per workgroup and log2(buckets per item) of the latest launch */
 int     kr_debug_isect(kr_ctx*, int64_t* out4);
+/* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
+int64_t kr_debug_budget_left(kr_ctx*);
+int     kr_debug_budget_set(kr_ctx*, int64_t left);
 int     kr_debug_info(kr_ctx*, int64_t* out8);  /* b, nbuckets, T, CAP, nwg, overflow segments, fallback launches, 0 */
 
 #ifdef __cplusplus

@@ -96,6 +96,8 @@ SYMBOLS = [
     ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
     ("kr_debug_isect", _c.c_int, [_P, _P]),
+    ("kr_debug_budget_left", _c.c_int64, [_P]),
+    ("kr_debug_budget_set", _c.c_int, [_P, _c.c_int64]),
 ]
 
 

@@ -9,17 +9,13 @@ the RCCL unique id and leaves it in a file the other ranks wait for -- so neithe
 MPI is needed; `torch.distributed.run` (or any launcher that sets RANK / LOCAL_RANK /
 WORLD_SIZE) merely starts the processes.
 
-The functions that take a `dist` argument are the same tree written over torch.distributed
-send / recv with host bounces.  They are not used by the product path any more; the CPU tests
-(tests/test_distributed.py, gloo, a CPU stand-in engine) keep them as the executable statement
-of the tree's semantics: "tree-reduce of per-rank lists == n-way intersection".
+(The same tree written over torch.distributed, the executable statement of its semantics --
+"tree-reduce of per-rank lists == n-way intersection" -- is test scaffolding and lives with the
+tests: tests/dist_tree_reference.py, driven over gloo by tests/test_distributed.py.)
 """
 import os
+import secrets
 import time
-
-import numpy as np
-
-from ._native import CAND
 
 
 def shard(items, rank, world):
@@ -28,12 +24,28 @@ def shard(items, rank, world):
 
 
 def env_rank_world():
-    """(rank, local_rank, world) as torch.distributed.run / mpirun / srun export them"""
+    """(rank, local_rank, world) as torch.distributed.run / mpirun / srun export them.  A launcher's
+    variables count only as a SET -- its size together with its rank: SLURM_NTASKS alone is set for
+    every process inside an salloc / sbatch allocation, also for a plain `python bench.py` there,
+    which is one rank of one.  KRISP_LAUNCHER = torchrun | mpi | slurm | none names the set to
+    read (none: always (0, 0, 1))."""
     e = os.environ
-    rank = int(e.get("RANK", e.get("OMPI_COMM_WORLD_RANK", e.get("SLURM_PROCID", "0"))))
-    world = int(e.get("WORLD_SIZE", e.get("OMPI_COMM_WORLD_SIZE", e.get("SLURM_NTASKS", "1"))))
-    local = int(e.get("LOCAL_RANK", e.get("OMPI_COMM_WORLD_LOCAL_RANK", e.get("SLURM_LOCALID", str(rank)))))
-    return rank, local, world
+    sets = {"torchrun": ("RANK", "WORLD_SIZE", "LOCAL_RANK"),
+            "mpi": ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK"),
+            "slurm": ("SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID")}
+    want = e.get("KRISP_LAUNCHER", "").strip().lower()
+    if want == "none":
+        return 0, 0, 1
+    if want and want not in sets:
+        raise ValueError(f"KRISP_LAUNCHER={want!r}: torchrun, mpi, slurm or none")
+    for name in ([want] if want else ["torchrun", "mpi", "slurm"]):
+        r, w, l = sets[name]
+        if r in e and w in e:
+            rank, world = int(e[r]), int(e[w])
+            if not 0 <= rank < world:
+                raise ValueError(f"{r}={rank} outside {w}={world}")
+            return rank, int(e.get(l, str(rank))), world
+    return 0, 0, 1
 
 
 def rendezvous_path(world):
@@ -47,130 +59,107 @@ def rendezvous_path(world):
     return os.path.join(tmp, f"krisp_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{world}")
 
 
+def _read(path):
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def _write_atomic(path, data):
+    """a reader never sees a partial file; the temporary name is ours alone (O_EXCL, mode 0600)"""
+    tmp = f"{path}.{os.getpid()}.{secrets.token_hex(4)}.tmp"
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def rendezvous(base, rank, world, payload=b"", timeout_s=600):
+    """Rank 0's `payload` and a per-run nonce for every rank, through files under `base`.rv --
+    proof against what an earlier, crashed run left there.  Rank r > 0 announces itself with a
+    fresh random token (join_r); rank 0 answers each token it sees with token + nonce + payload
+    (go_r) and re-answers when the token under join_r changes (it may first have read a stale
+    one); rank r accepts only an answer that starts with ITS token and acknowledges the nonce
+    (ack_r); rank 0 returns once every rank has acknowledged THIS nonce, then removes the files.
+    Returns (nonce, payload)."""
+    d = base + ".rv"
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    t0 = time.time()
+
+    def late(what):
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: {what} (rendezvous {d}, {timeout_s} s)")
+        time.sleep(0.003)
+
+    if world == 1:
+        return secrets.token_hex(8), payload
+    if rank == 0:
+        nonce = secrets.token_hex(8).encode()
+        answered = {}
+        while True:
+            for r in range(1, world):
+                tok = _read(os.path.join(d, f"join_{r}"))
+                if tok and len(tok) == 16 and answered.get(r) != tok:
+                    _write_atomic(os.path.join(d, f"go_{r}"), tok + nonce + payload)
+                    answered[r] = tok
+            if all(_read(os.path.join(d, f"ack_{r}")) == nonce for r in range(1, world)):
+                break
+            late("not every rank has joined")
+        for r in range(1, world):
+            for nm in (f"join_{r}", f"go_{r}", f"ack_{r}"):
+                try:
+                    os.unlink(os.path.join(d, nm))
+                except OSError:
+                    pass
+        return nonce.decode(), payload
+    tok = secrets.token_hex(8).encode()
+    _write_atomic(os.path.join(d, f"join_{rank}"), tok)
+    while True:
+        g = _read(os.path.join(d, f"go_{rank}"))
+        if g and g[:16] == tok:
+            break
+        late("no answer from rank 0")
+    nonce, payload = g[16:32], g[32:]
+    _write_atomic(os.path.join(d, f"ack_{rank}"), nonce)
+    return nonce.decode(), payload
+
+
 def connect(engine, rank, world, transport="rccl", path=None, timeout_s=600):
-    """Give `engine` its communicator.  transport "rccl": one GPU per rank, the unique id goes
-    through the file `path`; "dir": the rehearsal transport (messages through files in the
-    directory `path`; ranks may share a GPU)."""
+    """Give `engine` its communicator.  transport "rccl": one GPU per rank, rank 0's unique id
+    travels with the rendezvous; "dir": the rehearsal transport (messages through files, ranks
+    may share a GPU) in a directory named by the run's nonce, so no run ever reads another's
+    messages."""
     from . import _native
     path = path or rendezvous_path(world)
-    if transport == "dir":
-        engine.comm_init_dir(rank, world, path + ".d")
-        return
-    if transport != "rccl":
+    if transport not in ("rccl", "dir"):
         raise ValueError(f"unknown transport {transport!r}")
-    if world == 1:
+    if transport == "rccl" and world == 1:
         engine.comm_init(0, 1, _native.comm_unique_id())
         return
-    if rank == 0:
-        cid = _native.comm_unique_id()
-        with open(path + ".tmp", "wb") as f:
-            f.write(cid)
-        os.replace(path + ".tmp", path)            # (atomic: a reader never sees a partial id)
-    else:
-        t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout_s} s")
-            time.sleep(0.005)
-        with open(path, "rb") as f:
-            cid = f.read()
-    engine.comm_init(rank, world, cid)             # (collective: returns once every rank has joined)
-    if rank == 0:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
-
-
-# ----------------------------------------------------------------------------
-# the same tree over torch.distributed (CPU tests; see the module docstring)
-# ----------------------------------------------------------------------------
-def _to_tensor(arr, device):
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).reshape(-1).copy())
-    return t.to(device) if device is not None else t
-
-
-def _send(dist, arr, dst, device):
-    import torch
-    n = torch.tensor([len(arr)], dtype=torch.int64)
-    n = n.to(device) if device is not None else n
-    dist.send(n, dst)
-    if len(arr):
-        dist.send(_to_tensor(arr, device), dst)
-
-
-def _recv(dist, src, device, dtype):
-    import torch
-    n = torch.zeros(1, dtype=torch.int64)
-    n = n.to(device) if device is not None else n
-    dist.recv(n, src)
-    cnt = int(n.item())
-    words = dtype.itemsize // 8
-    if cnt == 0:
-        return np.empty(0, dtype=dtype)
-    buf = torch.empty(cnt * words, dtype=torch.int64)
-    buf = buf.to(device) if device is not None else buf
-    dist.recv(buf, src)
-    return buf.cpu().numpy().view(dtype)
-
-
-def tree_reduce_candidates(engine, dist, rank, world, apply_filter, device=None):
-    """Every rank holds the candidates of its own genomes in `engine` (unfiltered, or
-    already pruned with the diagnostic filter: the predicate "some column has disjoint
-    ingroup / outgroup base sets" is monotone -- masks only grow under merging -- so a
-    candidate that fails it on partial masks fails it globally and may be dropped at
-    any stage).  After the call rank 0 holds the candidates present on every rank, masks
-    OR-ed (and filtered when apply_filter); other ranks' candidate sets are spent.
-    Returns the final count on rank 0, -1 elsewhere.  log2(world) rounds."""
-    step = 1
-    active = True
-    while step < world:
-        if active:
-            if rank % (2 * step) == 0:
-                partner = rank + step
-                if partner < world:
-                    other = _recv(dist, partner, device, CAND)
-                    engine.merge_cands(other, apply_filter=apply_filter)
-            else:
-                _send(dist, engine.cands(), rank - step, device)
-                active = False
-        step *= 2
-    if rank == 0:
-        if apply_filter:
-            return engine.merge_cands(None, apply_filter=True)
-        return len(engine.cands())
-    return -1
-
-
-def broadcast_candidates(engine, dist, rank, world, device=None):
-    """Rank 0's final candidates -> every rank's engine (for the local collect)."""
-    import torch
-    if world == 1:
+    cid = _native.comm_unique_id() if (transport == "rccl" and rank == 0) else b""
+    nonce, cid = rendezvous(path, rank, world, bytes(cid), timeout_s)
+    if transport == "dir":
+        os.makedirs(path + ".d", mode=0o700, exist_ok=True)
+        engine.comm_init_dir(rank, world, os.path.join(path + ".d", nonce))
         return
-    cands = engine.cands() if rank == 0 else np.empty(0, dtype=CAND)
-    n = torch.tensor([len(cands)], dtype=torch.int64)
-    n = n.to(device) if device is not None else n
-    dist.broadcast(n, 0)
-    cnt = int(n.item())
-    buf = _to_tensor(cands, device) if rank == 0 else torch.empty(cnt * 3, dtype=torch.int64)
-    if rank != 0 and device is not None:
-        buf = buf.to(device)
-    if cnt:
-        dist.broadcast(buf, 0)
-    if rank != 0:
-        engine.load_cands(buf.cpu().numpy().view(CAND) if cnt else np.empty(0, dtype=CAND))
+    engine.comm_init(rank, world, cid)             # (collective: returns once every rank has joined)
 
 
-def gather_records(records, dist, rank, world, device=None):
-    """Per-rank (key, genome, count) records -> concatenation on rank 0."""
-    from ._native import RECORD
-    if world == 1:
-        return records
-    if rank == 0:
-        parts = [records]
-        for src in range(1, world):
-            parts.append(_recv(dist, src, device, RECORD))
-        return np.concatenate(parts)
-    _send(dist, records, 0, device)
-    return None
+def sharded_step(eng, ids, flags, world, apply_filter=True, collect=True):
+    """One pass of the sharded hot path on THIS rank (`eng` holds the rank's genomes `ids`, uploaded):
+    sort every genome, intersect them locally -- with the diagnostic filter already, which is safe: the
+    predicate is monotone --, then the ONE exchange (tree reduction of the candidate lists to rank 0,
+    csrc/h_comm.inc; the survivors broadcast) and the local collect of the survivors' records.
+    bench.py --gpus N times exactly this function, tests/test_gpu_fullsize.py runs it at world 8.
+    Returns (candidates after the reduction -- on rank 0 --, this rank's record count)."""
+    for g in ids:
+        eng.sort(g)
+    n = eng.intersect(ids, flags, apply_filter=apply_filter)
+    if world > 1:
+        n = eng.cands_reduce(apply_filter=apply_filter)
+        if collect:
+            eng.cands_bcast()
+    nrec = eng.collect(ids, fetch=False) if collect else 0          # (the records stay in HBM)
+    return n, nrec

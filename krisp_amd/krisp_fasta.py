@@ -969,12 +969,14 @@ def main(argv=None):
             print(f"({i}) {f}", file=sys.stderr)
         print(file=sys.stderr)
     devices = [int(x) for x in str(args.devices).split(",")] if getattr(args, "devices", None) else None
-    if devices and len(devices) > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    from . import distributed as _dist
+    launch_world = _dist.env_rank_world()[2]     # torchrun / mpirun / srun alike (one place decides: distributed.py)
+    if devices and len(devices) > 1 and launch_world == 1:
         # one process, a thread per device
         groups, stats = find_regions_multi_device(args.files, args.outgroup, args.conserved_left,
                                                   args.conserved_right, args.amplicon, devices,
                                                   omit_soft=args.omit_soft, verbose=args.verbose)
-    elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    elif launch_world > 1:
         # one process per GPU (python -m torch.distributed.run ... -m krisp_amd.krisp_fasta ...)
         groups, stats = find_regions_distributed(args.files, args.outgroup, args.conserved_left,
                                                  args.conserved_right, args.amplicon, omit_soft=args.omit_soft,

@@ -19,7 +19,9 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, os.environ["KR_ROOT"])
     import torch
     import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.environ["KR_ROOT"], "tests"))
     from krisp_amd import distributed as D, synth
+    import dist_tree_reference as T
     from krisp_amd._native import CAND, RECORD
     from oracle import kmer_oracle as K
 
@@ -60,13 +62,13 @@ WORKER = textwrap.dedent('''
     mine = D.shard(list(range(len(fam))), rank, world)
     keys = [K.sorted_keys(fam[g][2].tobytes(), L, Dg, R) for g in mine]
     eng = OracleEngine(keys, [fam[g][1] for g in mine])
-    n = D.tree_reduce_candidates(eng, dist, rank, world, apply_filter=True)
-    D.broadcast_candidates(eng, dist, rank, world)
+    n = T.tree_reduce_candidates(eng, dist, rank, world, apply_filter=True)
+    T.broadcast_candidates(eng, dist, rank, world)
     final = eng.cands()
     recs = K.collect(keys, final.astype(K.CAND), L, Dg, R) if len(final) else np.empty(0, K.RECORD)
     recs = recs.astype(RECORD)
     recs["genome"] = np.array(mine, dtype=np.uint32)[recs["genome"]] if len(recs) else recs["genome"]
-    allrec = D.gather_records(recs, dist, rank, world)
+    allrec = T.gather_records(recs, dist, rank, world)
     if rank == 0:
         allkeys = [K.sorted_keys(t.tobytes(), L, Dg, R) for _, _, t in fam]
         want = K.intersect(allkeys, [f for _, f, _ in fam], L, Dg, R, apply_filter=True)
@@ -120,3 +122,59 @@ def test_shard_is_round_robin():
     from krisp_amd.distributed import shard
     assert shard(list(range(10)), 1, 4) == [1, 5, 9]
     assert sum((shard(list(range(10)), r, 4) for r in range(4)), []).__len__() == 10
+
+
+def test_launcher_variables_count_only_as_a_set(monkeypatch):
+    """distributed.env_rank_world: SLURM_NTASKS alone (every process inside an allocation has it) is not a
+    launch; a launcher's size counts together with its rank; KRISP_LAUNCHER pins the set"""
+    from krisp_amd import distributed as D
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE",
+              "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID", "KRISP_LAUNCHER"):
+        monkeypatch.delenv(v, raising=False)
+    assert D.env_rank_world() == (0, 0, 1)
+    monkeypatch.setenv("SLURM_NTASKS", "8")
+    assert D.env_rank_world() == (0, 0, 1)
+    monkeypatch.setenv("SLURM_PROCID", "3")
+    monkeypatch.setenv("SLURM_LOCALID", "1")
+    assert D.env_rank_world() == (3, 1, 8)
+    monkeypatch.setenv("OMPI_COMM_WORLD_RANK", "2")
+    monkeypatch.setenv("OMPI_COMM_WORLD_SIZE", "4")
+    assert D.env_rank_world() == (2, 2, 4)                 # (mpirun inside the allocation: its own set wins)
+    monkeypatch.setenv("KRISP_LAUNCHER", "slurm")
+    assert D.env_rank_world() == (3, 1, 8)
+    monkeypatch.setenv("KRISP_LAUNCHER", "none")
+    assert D.env_rank_world() == (0, 0, 1)
+    monkeypatch.setenv("KRISP_LAUNCHER", "torchrun")
+    assert D.env_rank_world() == (0, 0, 1)
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(ValueError):
+        D.env_rank_world()
+
+
+def test_rendezvous_ignores_what_a_crashed_run_left(tmp_path):
+    """distributed.rendezvous: stale join / go / ack files of an earlier run under the same name change
+    nothing -- every rank gets rank 0's payload and ONE fresh nonce"""
+    import threading
+    from krisp_amd import distributed as D
+    base = str(tmp_path / "rv")
+    os.makedirs(base + ".rv")
+    for r in (1, 2):
+        open(os.path.join(base + ".rv", f"join_{r}"), "wb").write(b"0123456789abcdef")
+        open(os.path.join(base + ".rv", f"go_{r}"), "wb").write(b"0123456789abcdef" + b"f" * 16 + b"stale payload")
+        open(os.path.join(base + ".rv", f"ack_{r}"), "wb").write(b"f" * 16)
+    for trial in range(2):                                # (and a second run under the same name)
+        out = [None] * 3
+
+        def work(rank):
+            out[rank] = D.rendezvous(base, rank, 3, b"payload of rank 0" if rank == 0 else b"", timeout_s=20)
+
+        ts = [threading.Thread(target=work, args=(r,)) for r in (2, 1, 0)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(30)
+        assert all(o is not None for o in out)
+        assert {o[1] for o in out} == {b"payload of rank 0"}
+        assert len({o[0] for o in out}) == 1 and out[0][0] != "f" * 16
+    assert os.listdir(base + ".rv") == []

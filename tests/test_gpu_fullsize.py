@@ -6,8 +6,12 @@ collect in every genome, agreement between slicing configurations.
   * BASELINE configs[1] (4 x 50 Mbp, 25/1/2), configs[2] (8 x 500 Mbp, 32/60/32: the wide path) and
     configs[4] (2 x 3 Gbp, k = 31 as 28/1/2; 64 key-space slices, ~150 GB of HBM) all run in the
     regular `-m gpu` suite (KR_SKIP_BIG=1 leaves the two large ones out: ~2 minutes of host-side
-    genome generation each).  configs[3] (32 genomes on 8 GPUs) needs the 8-GPU node; its
-    per-GPU load and its whole genome set on one GPU are bench.py variants (profiles/).
+    genome generation each).
+  * BASELINE configs[3] (32 x 100 Mbp sharded over 8 GPUs): its whole genome set on ONE GPU through the same
+    properties, and the same family sharded 4 per rank over WORLD 8 -- eight contexts sharing the test GPU, the
+    exchange over the file transport -- through the very function bench.py --gpus 8 times
+    (distributed.sharded_step), the result equal to the one-GPU run bit for bit.  What this cannot show is RCCL
+    itself between eight devices (no such node for the builder: DESIGN.md "Multi-GPU").
 """
 import os
 
@@ -232,3 +236,100 @@ def test_wide_run_at_scale_properties():
         pairs.append((g[0].left, g[0].right))
     assert pairs == sorted(pairs) and len(set(pairs)) == len(pairs)
     assert info["ng"] >= len(g1)
+
+
+@BIG
+def test_c4_thirty_two_genomes_on_one_gpu_and_sharded_over_world_eight(tmp_path, monkeypatch):
+    """BASELINE configs[3]: 32 x 100 Mbp (16 in / 16 out), 25/1/2 -- (a) all on one GPU (64 GB of keys, one 32-way
+    intersection) through the full-size properties; (b) sharded 4 per rank over world 8 with bench.py's own
+    layout and step function, eight contexts on this GPU talking through the file transport: candidates and
+    records equal (a)'s; (c) the calls of that step are the library's exchange entry points, in bench.py's order"""
+    import inspect
+    import threading
+    import time
+    import bench
+    from krisp_amd import _native
+    from krisp_amd import distributed as DD
+    L, D, R = 25, 1, 2
+    world, per = 8, 4
+    t0 = time.time()
+    shards = [bench.make_genomes(4, r, world, per, 100_000_000) for r in range(world)]      # (SURVEY 8d: config# 4)
+    t1 = time.time()
+    fam = [(f"g{g}", ing, text) for sh in shards for g, ing, text in sh]
+    assert [g for sh in shards for g, _, _ in sh] == list(range(world * per))
+    # (a) one GPU, one context: the properties (filtered), then candidates + records without and with the filter
+    # (unfiltered: ~3e4 groups conserved in all 32 genomes; filtered: the handful of them that hold a planted SNP)
+    c1, info = _run(fam, L, D, R)
+    assert info["overflow_segments"] == 0 and len(c1) >= 1
+    one = {}
+    with _native.Engine() as eng:
+        eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            eng.upload(i, t)
+            eng.sort(i)
+        flags = [f for _, f, _ in fam]
+        for filt in (False, True):
+            n = eng.intersect(list(range(len(fam))), flags, apply_filter=filt)
+            one[filt] = (eng.cands().copy(), eng.collect(list(range(len(fam)))).copy())
+            assert n == len(one[filt][0])
+    assert np.array_equal(one[True][0], c1) and len(one[False][0]) > 5000
+    t2 = time.time()
+    # (b) world 8: a thread per rank (the library calls release the GIL), every rank its own context on this GPU
+    monkeypatch.setenv("KR_PLACE_TRIES", "1")           # (eight contexts at once: no need to try 8 x 8 buffers)
+    out, errs, calls = [None] * world, [None] * world, [None] * world
+    comm_dir = str(tmp_path / "comm")
+
+    class Recorder:
+        """the engine, with the names of the calls sharded_step makes on it"""
+        def __init__(self, eng, log):
+            self._e, self._log = eng, log
+        def __getattr__(self, name):
+            attr = getattr(self._e, name)
+            if not callable(attr):
+                return attr
+            def call(*a, **k):
+                self._log.append(name)
+                return attr(*a, **k)
+            return call
+
+    def work(rank):
+        try:
+            with _native.Engine() as eng:
+                eng.comm_init_dir(rank, world, comm_dir)
+                eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in shards[rank]))
+                ids = [g for g, _, _ in shards[rank]]
+                for g, _, t in shards[rank]:
+                    eng.upload(g, t)
+                res = {}
+                for filt in (False, True):
+                    log = []
+                    n, nrec = DD.sharded_step(Recorder(eng, log), ids, [f for _, f, _ in shards[rank]], world,
+                                              apply_filter=filt)
+                    calls[rank] = log
+                    cands = eng.cands().copy()
+                    total = eng.records_gather()
+                    res[filt] = (n, cands, eng.fetch_records(total) if rank == 0 else None)
+                    eng.comm_barrier()
+                out[rank] = res
+        except BaseException as e:  # noqa: BLE001
+            errs[rank] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errs == [None] * world, errs
+    for filt in (False, True):
+        cand1, rec1 = one[filt]
+        assert out[0][filt][0] == len(cand1)
+        for r in range(world):                         # (the broadcast gave every rank the survivors)
+            assert np.array_equal(out[r][filt][1], cand1), (filt, r)
+        assert np.array_equal(np.sort(out[0][filt][2], order=["key", "genome"]), np.sort(rec1, order=["key", "genome"]))
+    # (c) the same entry points in the same order on every rank, and bench.py times this very function
+    want = ["sort"] * per + ["intersect", "cands_reduce", "cands_bcast", "collect"]
+    assert all(c == want for c in calls), calls
+    assert "D.sharded_step(eng, ids, flags, world" in inspect.getsource(bench.main)
+    print(f"\nconfigs[3]: {len(one[False][0])} / {len(c1)} candidates without / with the filter, {len(one[False][1])} / "
+          f"{len(one[True][1])} records; generation {t1 - t0:.0f} s, one GPU {t2 - t1:.0f} s, "
+          f"world 8 {time.time() - t2:.0f} s")

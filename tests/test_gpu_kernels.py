@@ -526,3 +526,51 @@ def test_stage_timers_and_medium_size(N, K):
         assert np.array_equal(e.cands()["prefix"], want["prefix"])
         for i in range(4):
             assert np.array_equal(e.keys(i), want_keys[i])
+
+
+def test_exchange_is_all_or_none_when_a_rank_runs_out_of_memory(N, K, tmp_path):
+    """kr_cands_reduce / kr_cands_bcast / kr_records_gather: a rank whose allocation fails between a count and
+    the list it announces (here: rank 0's HBM budget is too small for the list rank 1 sends) answers that count
+    with "no", keeps its place in the tree and returns its error; no rank is left inside a send or a receive
+    (over RCCL those have no timeout).  Three ranks as threads over the file transport."""
+    import threading
+    import time
+    L, D, R = 12, 1, 3
+    fam = _family(21, 6, 60_000, mu=0.002)
+    world = 3
+    res, errs = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            with N.Engine() as e:
+                e.comm_init_dir(rank, world, str(tmp_path / "comm"))
+                e.set_params(L, D, R, max_bases=60_100)
+                ids = [g for g in range(len(fam)) if g % world == rank]
+                for g in ids:
+                    e.upload(g, fam[g][2])
+                    e.sort(g)
+                e.intersect(ids, [fam[g][1] for g in ids], apply_filter=False)
+                if rank == 0:
+                    # rank 0 holds its genomes and scratch, but from now on not one candidate list more
+                    assert e.lib.kr_debug_budget_set(e.ctx, 1) == 0 and e.lib.kr_debug_budget_left(e.ctx) == 1
+                try:
+                    e.cands_reduce(apply_filter=False)
+                    res[rank] = "reduced"
+                    e.cands_bcast()
+                    res[rank] = "bcast"
+                except N.KrispHipError as ex:
+                    res[rank] = f"error: {ex}"
+        except BaseException as ex:  # noqa: BLE001
+            errs[rank] = ex
+
+    ts = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+    t0 = time.time()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not any(t.is_alive() for t in ts), f"a rank hangs: {res}"
+    assert errs == [None] * world, errs
+    assert res[0].startswith("error:") and "budget" in res[0], res
+    assert all(r.startswith("error:") for r in res), res            # (ranks 1 and 2: "rank 0 failed", from its answers)
+    assert time.time() - t0 < 50
