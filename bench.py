@@ -60,24 +60,38 @@ REFERENCE_PYTHON = {"value": 1.04e5, "unit": "k-mers/s", "cores": 8,
                              "not on the GPU box: the reference cannot travel there"}
 
 
-def baseline_config_name(world, per_gpu, length, ldr, independent, masked):
-    """which BASELINE.json config the arguments are (or "custom")"""
-    L, D, R = ldr
-    plain = not independent and not masked
-    if plain and world == 1 and per_gpu == 4 and length == 50_000_000 and ldr == [25, 1, 2]:
-        return "BASELINE configs[1]"
-    if plain and world == 8 and per_gpu == 4 and length == 100_000_000 and ldr == [25, 1, 2]:
-        return "BASELINE configs[3]"
-    if plain and world == 1 and per_gpu == 2 and length == 3_000_000_000 and ldr == [28, 1, 2]:
-        return "BASELINE configs[4]"
-    if plain and per_gpu == 4 and length == 50_000_000 and ldr == [25, 1, 2]:
-        return f"BASELINE configs[1] per GPU, weak-scaled to {world} GPUs"
-    if world == 1 and per_gpu == 4 and length == 50_000_000 and ldr == [25, 1, 2]:
-        return "BASELINE configs[1] geometry, SURVEY 8(d) secondary input"
-    return "custom (not a BASELINE.json config)"
+# BASELINE.json `configs` by index (--config N): the label of a bench line comes from this table, never from a
+# guess about the arguments.  `gen` = SURVEY 8(d)'s config# (ancestor seed 1000 + config#: C2..C5 = configs[1..4]);
+# mu / records / snp_every are 8(d)'s generator (0.01 / 16 / 10 kb) for every config.
+CONFIGS = {
+    1: dict(per_gpu=4, length=50_000_000, ldr=[25, 1, 2], gen=2, gpus=1,
+            what="4 synthetic 50 Mbp random genomes (2 in / 2 out), k=28 spacer search, 1 x MI355X"),
+    2: dict(per_gpu=8, length=500_000_000, ldr=[32, 60, 32], gen=3, gpus=1,
+            what="8 synthetic 500 Mbp genomes (4 in / 4 out), 32/60/32 amplicon search, 1 x MI355X"),
+    3: dict(per_gpu=4, length=100_000_000, ldr=[25, 1, 2], gen=4, gpus=8,
+            what="32 synthetic 100 Mbp genomes, 4 per GPU on 8 x MI355X, k=28, candidate exchange over RCCL"),
+    4: dict(per_gpu=2, length=3_000_000_000, ldr=[28, 1, 2], gen=5, gpus=1,
+            what="2 synthetic 3 Gbp human-scale genomes (1 in / 1 out), k=31, 1 x MI355X, key-space slices"),
+}
 
 
-def make_genomes(config, rank, world, per_rank, length, independent=False, masked=False):
+def baseline_config_name(cfg, custom, world, independent, masked, mu, records, snp_every):
+    """the label: BASELINE configs[N] only when every argument is that config's"""
+    if custom:
+        return "custom (not a BASELINE.json config)"
+    name = f"BASELINE configs[{cfg}]"
+    gen_8d = (mu, records, snp_every) == (0.01, 16, 10000)
+    if independent or masked:
+        return name + " geometry, SURVEY 8(d) secondary input"
+    if not gen_8d:
+        return name + f" geometry, generator mu={mu:g} / {records} records / SNP per {snp_every} (8(d): 0.01 / 16 / 10000)"
+    if world != CONFIGS[cfg]["gpus"]:
+        return name + (f" per-GPU load, weak-scaled to {world} GPUs" if world > 1 else " per-GPU load on one GPU")
+    return name
+
+
+def make_genomes(config, rank, world, per_rank, length, independent=False, masked=False, mu=0.01, records=16,
+                 snp_every=10000):
     from krisp_amd import synth
     anc = None if independent else synth.ancestor(config, length)
     out = []
@@ -85,10 +99,10 @@ def make_genomes(config, rank, world, per_rank, length, independent=False, maske
         # every rank holds half ingroup / half outgroup genomes of the 4N-genome family, so the
         # diagnostic filter can already prune locally (it is monotone: DESIGN.md "Multi-GPU")
         ing = (g % per_rank) < per_rank // 2
-        codes = synth.genome_codes(config, g, length, ing, mu=0.01, snp_every=10000,
+        codes = synth.genome_codes(config, g, length, ing, mu=mu, snp_every=snp_every,
                                    independent=independent, anc=anc)
         # --masked = SURVEY 8(d) secondary variant (ii): 0.1 % of the bases N in 1 kb runs, 5 % lower case
-        out.append((g, ing, synth.codes_to_text(codes, records=16, n_frac=0.001 if masked else 0.0,
+        out.append((g, ing, synth.codes_to_text(codes, records=records, n_frac=0.001 if masked else 0.0,
                                                 lower_frac=0.05 if masked else 0.0, seed=100 * config + g)))
     return out
 
@@ -164,17 +178,67 @@ def cpu_baseline(config, L, D, R, length, full_length, per_gpu):
     return out
 
 
+# The wide path (amplicons longer than one key: BASELINE configs[2]) -- ALGORITHMIC bytes per k-mer record of its
+# stages over ONE kr_wide_run with L = R (one flank spectrum serves both flanks, one canonical
+# composite key per window start = half a key per record).  Streamed bytes as the kernels' arguments say; a
+# dictionary look-up = one 32-byte DRAM sector (the unit the memory system moves, tools/randbench.hip).
+WIDE_STAGE_BYTES = {
+    "pack": 2 * (0.5 + 0.1875),     # both phases pack the genome again
+    "hist8": 0.1875 + 8.0 + (0.1875 + 2 * 32 / 2 + 8.0) + 2 * 8.0,   # spectrum keys from the codes (pass 0 + slices read
+                                    # them), composite keys: 2 look-ups and a 16-byte cache line per window start, the
+                                    # slices' histograms over the pass-0 arrays of both phases
+    "scatter1": (0.1875 + 8.0 + 16.0) + (8.0 + 4.0 + 8.0),            # pass 0 + pass 1 of the spectrum; the composite phase
+                                    # from the cache, half a key per record
+    "scatter2": 16.0 + 8.0,
+    "localsort": 16.0 + 8.0,
+    "hist2": 8.0 + 4.0,             # (key-space slices: fine offsets from the pass-1 output)
+    "intersect": 8.0 + 4.0,
+    "locate": 8.0 + 32 / 2 + 8.0,   # cached key + group look-up per window start + the window's group written back
+}
+
+
+def cpu_baseline_wide(gen, L, D, R, per_gpu, mu, records, snp_every):
+    """the reference's own text pipeline as restated in oracle/krisp_oracle.py (kstream -> sort -> merge tree ->
+    filter -> render, pure Python, one core) on a down-scaled family of the same generator and geometry"""
+    import tempfile
+    from oracle import krisp_oracle as O
+    from krisp_amd import synth
+    length = 40_000
+    with tempfile.TemporaryDirectory(prefix="krisp_bench_") as td:
+        fam = make_genomes(gen, 0, 1, per_gpu, length, mu=mu, records=min(records, 4), snp_every=min(snp_every, 5000))
+        ing, outg = [], []
+        for g, is_in, text in fam:
+            f = os.path.join(td, ("in" if is_in else "out") + f"{g}.fasta")
+            synth.write_fasta(f, text)
+            (ing if is_in else outg).append(f)
+        t0 = time.perf_counter()
+        res = O.run_krisp_fasta(ing, outg, L, D, R)
+        dt = time.perf_counter() - t0
+        n = sum(len(v) for v in res["sorted"].values())
+    return {"value": n / dt, "unit": "k-mers/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{per_gpu} x {length / 1e3:g} kbp genomes of the same generator, {L}/{D}/{R}: {n} k-mer records in "
+                      f"{dt:.1f} s through oracle/krisp_oracle.py (the reference's text pipeline restated: per-character "
+                      f"Python, sorted text lines, pairwise merge tree), one core",
+            "reference_python": REFERENCE_PYTHON}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 2 for the multi-GB configs 2 and 4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 2; 1 for configs 2 and 4)")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[N]: 1 = 4 x 50 Mbp 25/1/2 (default; at --gpus 8: 3 = 4 x 100 Mbp per GPU), "
+                         "2 = 8 x 500 Mbp 32/60/32 (wide path), 4 = 2 x 3 Gbp 28/1/2")
     ap.add_argument("--place-tries", type=int, default=None,
                     help="KR_OPT_PLACE_TRIES: candidate allocations of the pass-1 output buffer, the fastest is kept "
                          "(default: the library's own default, 8 -- what the command line runs with, too)")
-    ap.add_argument("--length", type=int, default=50_000_000, help="bases per genome (C2: 50 Mbp)")
-    ap.add_argument("--per-gpu", type=int, default=4, help="genomes per GPU")
-    ap.add_argument("--ldr", type=int, nargs=3, default=[25, 1, 2])
+    ap.add_argument("--length", type=int, default=None, help="bases per genome (overrides the config's: a custom workload)")
+    ap.add_argument("--per-gpu", type=int, default=None, help="genomes per GPU (overrides the config's)")
+    ap.add_argument("--ldr", type=int, nargs=3, default=None, help="conserved-left diagnostic conserved-right")
+    ap.add_argument("--mu", type=float, default=0.01, help="substitution rate of the generator (SURVEY 8(d): 0.01)")
+    ap.add_argument("--records", type=int, default=16, help="FASTA records per genome (8(d): 16)")
+    ap.add_argument("--snp-every", type=int, default=10000, help="planted ingroup / outgroup SNP spacing (8(d): 10 kb)")
     ap.add_argument("--independent", action="store_true", help="independent random genomes")
     ap.add_argument("--masked", action="store_true", help="0.1 %% N in 1 kb runs + 5 %% lower case (soft-mask mapped)")
     ap.add_argument("--cpu-length", type=int, default=0,
@@ -199,10 +263,24 @@ def main():
     if args.transport == "dir":
         local_rank = 0                          # rehearsal: the ranks share the GPU
 
-    L, Dg, R = args.ldr
+    cfg = args.config if args.config is not None else (3 if world == 8 else 1)
+    C = CONFIGS[cfg]
+    custom = args.length is not None or args.per_gpu is not None or args.ldr is not None
+    length = args.length if args.length is not None else C["length"]
+    per_gpu = args.per_gpu if args.per_gpu is not None else C["per_gpu"]
+    L, Dg, R = args.ldr if args.ldr is not None else C["ldr"]
     k = L + Dg + R
-    config = 2
-    genomes = make_genomes(config, rank, world, args.per_gpu, args.length, args.independent, args.masked)
+    wide = k > 32 or Dg > 16
+    if wide and world > 1:
+        print("bench.py: the wide path (k > 32) is benchmarked on one GPU (DESIGN.md 7)", file=sys.stderr)
+        sys.exit(2)
+    big = length * per_gpu >= 2_000_000_000
+    steps = args.steps if args.steps is not None else (2 if big else 5)
+    warmup = args.warmup if args.warmup is not None else (1 if big else 2)
+    args.steps, args.warmup = steps, warmup
+    config = C["gen"]
+    genomes = make_genomes(config, rank, world, per_gpu, length, args.independent, args.masked,
+                           mu=args.mu, records=args.records, snp_every=args.snp_every)
     eng = _native.Engine(device=local_rank)
     comm = world > 1 or args.force_comm
     if comm:
@@ -212,7 +290,11 @@ def main():
     if args.place_tries is not None:
         eng.set_option(_native.OPT_PLACE_TRIES, args.place_tries)
     place_tries = args.place_tries if args.place_tries is not None else int(os.environ.get("KR_PLACE_TRIES", "8"))
-    eng.set_params(L, Dg, R, omit_soft=False, max_bases=max(len(t) for _, _, t in genomes))
+    max_bases = max(len(t) for _, _, t in genomes)
+    if wide:
+        eng.set_params_wide(L, Dg, R, omit_soft=False, max_bases=max_bases)
+    else:
+        eng.set_params(L, Dg, R, omit_soft=False, max_bases=max_bases)
     ids = []
     for g, ing, text in genomes:
         eng.upload(g, text)            # inputs resident in HBM before the timed region
@@ -229,8 +311,15 @@ def main():
     nrec = [0]
 
     def step():
+        if wide:
+            # one kr_wide_run: flank spectra -> dictionaries -> composite keys -> sort + intersect -> locate ->
+            # filter -> hits (group, genome, position, strand) resident in HBM
+            nrec[0] = eng.wide_run(ids, flags, apply_filter=True)
+            return int(eng.wide_fetch(_native.WIDE_NGROUPS)[0])
         n, nrec[0] = D.sharded_step(eng, ids, flags, world, apply_filter=True, collect=not args.no_collect)
         return n
+
+    stage_bytes_all = WIDE_STAGE_BYTES if wide else STAGE_BYTES
 
     for _ in range(args.warmup):
         step()
@@ -248,7 +337,7 @@ def main():
             step()
         barrier()
         calib = {s: (v[0] / ncal, v[1] // ncal) for s, v in eng.stage_times().items() if v[1]}
-        dom_stage = max((s for s in calib if s in STAGE_BYTES), key=lambda s: calib[s][0])
+        dom_stage = max((s for s in calib if s in stage_bytes_all), key=lambda s: calib[s][0])
         eng.stage_select([dom_stage])
         eng.stage_reset()
         barrier()
@@ -259,7 +348,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     stages = eng.stage_times() if not args.no_stage_timers else {}
-    kmers_local = sum(eng.count(g) for g in ids)
+    kmers_local = int(sum(eng.wide_fetch(_native.WIDE_COUNTS))) if wide else sum(eng.count(g) for g in ids)
     copy_gbps = eng.copy_gbps(1 << 30, 10) if rank == 0 else None      # measured streaming-copy rate of this box
 
     if comm and world > 1:
@@ -272,7 +361,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = kmers_total * args.steps / dt
-        model_b = model_bytes_per_kmer(k)
+        model_b = 696.5 if wide else model_bytes_per_kmer(k)      # (128-bit key + position payload for 32/60/32)
         # dominant kernel stage of this rank (HIP events on the engine's stream)
         roof = None
         if stages:
@@ -283,8 +372,8 @@ def main():
             # genomes (per slice) for the intersect.  Sliced genomes (> 4.2e8 keys) take one more pass:
             # their pass 0 writes all keys once (0.19 + 8 B), every slice's pass 1 reads and writes them
             nslices = eng.debug_info()["nslices"]
-            stage_bytes = dict(STAGE_BYTES)
-            if nslices > 1:
+            stage_bytes = dict(stage_bytes_all)
+            if nslices > 1 and not wide:
                 stage_bytes["scatter1"] = 0.1875 + 8.0 + 16.0
                 stage_bytes["hist8"] = 0.1875 + 8.0
             per_launch = kmers_local * args.steps / launches
@@ -293,11 +382,15 @@ def main():
             # FETCH_SIZE / WRITE_SIZE passes of this command, profiles/make_traffic.py), valid for
             # the default workload only; expressed like `achieved`: bytes per launch / launch time
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile) and args.length == 50_000_000 and args.per_gpu == 4 and [L, Dg, R] == [25, 1, 2]:
+            tfile = os.path.join(ROOT, "profiles", "traffic_wide.json" if wide else "traffic.json")
+            if os.path.exists(tfile) and not custom and cfg in (1, 2) and world == 1:
                 try:
                     tb = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
-                    traffic = round(tb / (avg_ms * 1e-3) / 1e9, 1) if tb else None
+                    if wide:                # (launch sizes differ by phase and slice: bytes and time per STEP there)
+                        tb = json.load(open(tfile)).get(dom, {}).get("bytes_per_step")
+                        traffic = round(tb / (ms / args.steps * 1e-3) / 1e9, 1) if tb else None
+                    else:
+                        traffic = round(tb / (avg_ms * 1e-3) / 1e9, 1) if tb else None
                 except Exception:  # noqa: BLE001
                     traffic = None
             roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -310,20 +403,22 @@ def main():
                     "pipeline_model_GBps": round(model_b * value / world / 1e9, 1),
                     "pipeline_model_frac": round(model_b * value / world / 1e9 / HBM_PEAK_GBPS, 4),
                     "stage_ms_per_step_calibration": {s: round(v[0], 4) for s, v in calib.items()}}
-        name = baseline_config_name(world, args.per_gpu, args.length, [L, Dg, R], args.independent, args.masked)
+        name = baseline_config_name(cfg, custom, world, args.independent, args.masked, args.mu, args.records, args.snp_every)
         out = {
             "metric": f"k-mers/s sorted+intersected at k={k}", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{name}: {args.per_gpu} synthetic {args.length / 1e6:g} Mbp random "
-                                   f"genomes per GPU (half in / half out over the {args.per_gpu * world}-genome "
-                                   f"family, mu=0.01, planted SNP / 10 kb"
+            "config": {"workload": f"{name}: {per_gpu} synthetic {length / 1e6:g} Mbp random "
+                                   f"genomes per GPU (half in / half out over the {per_gpu * world}-genome "
+                                   f"family, mu={args.mu:g}, {args.records} records, planted SNP / {args.snp_every}"
                                    + (", independent genomes" if args.independent else "")
                                    + (", 0.1 % N runs + 5 % lower case" if args.masked else "")
                                    + f"), {L}/{Dg}/{R} (k={k})",
-                       "baseline_config": name,
-                       "step": "sort every genome + n-way intersect + filter"
+                       "baseline_config": name, "baseline_text": None if custom else C["what"],
+                       "step": ("one kr_wide_run: flank spectrum + dictionaries + composite keys, sort + n-way intersect, "
+                                "locate + filter + hits (resident in HBM)") if wide else
+                               "sort every genome + n-way intersect + filter"
                                + ("" if args.no_collect else " + collect the candidate records (resident in HBM)"),
                        "kmers_per_step": kmers_total, "candidates": int(ncand), "records": int(records_total),
                        "place_tries": place_tries,
@@ -331,8 +426,10 @@ def main():
                                       f" + tree-reduce of candidates ({args.transport})")},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(config, L, Dg, R, args.cpu_length, args.length, args.per_gpu)
+        if world == 1 and not args.no_cpu_baseline and wide:
+            out["cpu_baseline"] = cpu_baseline_wide(config, L, Dg, R, per_gpu, args.mu, args.records, args.snp_every)
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(config, L, Dg, R, args.cpu_length, length, per_gpu)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

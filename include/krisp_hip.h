@@ -235,6 +235,18 @@ void    kr_host_free(void* p);
 int64_t kr_scan_special(const uint8_t* bases, size_t n, int k, int omit_soft, uint64_t* starts, size_t cap,
                         int* bad_char);
 
+/* Final text from survivor records of packed keys -- replaces Amplicon.py:523-671 (render_alignment, render_csv,
+ * makeBracket, consensus) and outputAlignments.py:26-162 at --cores 1 for large results: the CSV and the alignment
+ * blocks as bytes, one pass, no object per Amplicon (krisp_amd/amplicon.py keeps the general path; the tests run
+ * both and compare byte for byte).  recs ordered by (key, label id); label_of[genome] = rank of the genome's label
+ * among the distinct labels in string order; label_in[label] = 1 for ingroup labels, NULL when no outgroup was
+ * given.  Host only.  Returns the number of groups, KR_ERR_HOST for a group this code leaves to the general path
+ * (no all-ingroup row for the CSV consensus: the reference raises there).  Free the texts with kr_text_free. */
+int64_t kr_render_records(const kr_record* recs, size_t n, int L, int D, int R, const uint32_t* label_of,
+                          size_t n_genomes, const char* const* label_text, size_t n_labels, const uint8_t* label_in,
+                          int dot, char** csv, size_t* csv_len, char** align, size_t* align_len);
+void    kr_text_free(void* p);
+
 /* Options that change HOW (never what) the library computes; results are identical for every
  * value (tests run the suite under each).  Set after kr_create, before kr_set_params. */
 enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in 4^n key-space slices (the

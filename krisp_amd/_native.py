@@ -95,6 +95,9 @@ SYMBOLS = [
     ("kr_debug_intersect", _c.c_double, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int]),
     ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
+    ("kr_render_records", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _c.c_size_t, _P,
+                                       _c.c_int, _P, _P, _P, _P]),
+    ("kr_text_free", None, [_P]),
     ("kr_debug_isect", _c.c_int, [_P, _P]),
     ("kr_debug_budget_left", _c.c_int64, [_P]),
     ("kr_debug_budget_set", _c.c_int, [_P, _c.c_int64]),
@@ -181,6 +184,32 @@ def ingest_file(path):
     timings = dict(read_s=stats[4] / 1e6, inflate_s=stats[5] / 1e6, parse_s=stats[6] / 1e6,
                    members=int(stats[7] & 0xFFFFFFFF), libdeflate=bool(stats[7] >> 32))
     return arr, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3]), timings
+
+
+def render_records(records, label_of, label_text, label_in, L, D, R, dot=False):
+    """kr_render_records: (csv_text, alignment_text, number of groups), or None when the library leaves a group to
+    the general path.  records: RECORD array ordered by (key, label id); label_of: genome id -> label id;
+    label_text: the distinct labels in string order; label_in: per label 1 / 0, or None (no outgroup given)."""
+    lib = load()
+    recs = np.ascontiguousarray(records, dtype=RECORD)
+    lof = np.ascontiguousarray(label_of, dtype=np.uint32)
+    texts = [t.encode() for t in label_text]
+    arr = (_c.c_char_p * max(len(texts), 1))(*texts)
+    lin = None if label_in is None else np.ascontiguousarray(label_in, dtype=np.uint8)
+    csv, align = _c.c_void_p(), _c.c_void_p()
+    ncsv, nalign = _c.c_size_t(), _c.c_size_t()
+    rc = lib.kr_render_records(_ptr(recs), len(recs), L, D, R, _ptr(lof), len(lof), arr, len(texts),
+                               None if lin is None else _ptr(lin), 1 if dot else 0, _c.byref(csv), _c.byref(ncsv),
+                               _c.byref(align), _c.byref(nalign))
+    if rc == ERR_HOST:
+        return None
+    if rc < 0:
+        raise KrispHipError(f"kr_render_records: [{rc}]")
+    try:
+        return (_c.string_at(csv, ncsv.value).decode("ascii"), _c.string_at(align, nalign.value).decode("ascii"), int(rc))
+    finally:
+        lib.kr_text_free(csv)
+        lib.kr_text_free(align)
 
 
 def comm_unique_id():

@@ -75,6 +75,61 @@ class Amplicon:
         return f"{self.sequence} : {self.label_string()}"
 
 
+def _ordered_records(records, labels):
+    """the records in (key, rank of the genome's label) order: every Amplicon's label list is then born sorted.
+    kr_collect returns (key, position of the genome in the call) order: callers that list the genomes by label
+    get records that need no sort (one vectorised check instead of a lexsort)."""
+    by_name = np.argsort(np.array(labels, dtype=object), kind="stable")
+    label_rank = np.empty(len(labels), dtype=np.int64)
+    label_rank[by_name] = np.arange(len(labels))
+    rk = label_rank[records["genome"].astype(np.int64)]
+    kk = records["key"]
+    in_order = len(kk) < 2 or bool(np.all((kk[1:] > kk[:-1]) | ((kk[1:] == kk[:-1]) & (rk[1:] >= rk[:-1]))))
+    return records if in_order else records[np.lexsort((rk, kk))]
+
+
+class RecordGroups:
+    """The surviving groups as the device left them -- (key, genome, count) records -- behind the interface of the
+    list of groups groups_from_records() makes of them.  render() turns it into text in the library, in one pass
+    over the records (kr_render_records: no object per Amplicon); anything else that walks the
+    groups -- the Primer3 hook, the merged-file writer, tests -- gets the list, built on first use."""
+
+    def __init__(self, records, labels, L, D, R):
+        self.records = _ordered_records(records, labels) if len(records) else records
+        self.labels, self.L, self.D, self.R = list(labels), L, D, R
+        self._groups = None
+        if len(self.records):
+            pre = self.records["key"] & codec.prefix_mask(L, R)
+            self._n = 1 + int(np.count_nonzero(pre[1:] != pre[:-1]))
+        else:
+            self._n = 0
+
+    def groups(self):
+        if self._groups is None:
+            self._groups = groups_from_records(self.records, self.labels, self.L, self.D, self.R)
+        return self._groups
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self.groups())
+
+    def __getitem__(self, i):
+        return self.groups()[i]
+
+    def render_text(self, ingroup_labels, dot=False):
+        """-> (csv, alignment) through the library, or None when it leaves a group to the general path"""
+        from . import _native
+        distinct = sorted(set(self.labels))
+        rank = {t: i for i, t in enumerate(distinct)}
+        label_of = np.array([rank[t] for t in self.labels], dtype=np.uint32)
+        label_in = None if ingroup_labels is None else np.array([1 if t in ingroup_labels else 0 for t in distinct],
+                                                                dtype=np.uint8)
+        out = _native.render_records(self.records, label_of, distinct, label_in, self.L, self.D, self.R, dot)
+        return None if out is None else (out[0], out[1])
+
+
 def groups_from_records(records, labels, L, D, R, rna=False):
     """(key, genome, count) records of the survivors -> list of groups (lists of
     Amplicon), groups ascending by (left,right), Amplicons ascending by diag --
@@ -82,23 +137,8 @@ def groups_from_records(records, labels, L, D, R, rna=False):
     ConservedEndAmplicons.add() preserves (Amplicon.py:448-481)."""
     if len(records) == 0:
         return []
-    # records ordered by (key, rank of the genome's label): every Amplicon's label list is then born
-    # sorted (lexsort on columns is ~2x a structured sort)
-    by_name = np.argsort(np.array(labels, dtype=object), kind="stable")
-    label_rank = np.empty(len(labels), dtype=np.int64)
-    label_rank[by_name] = np.arange(len(labels))
-    rk = label_rank[records["genome"].astype(np.int64)]
-    kk = records["key"]
-    # kr_collect returns (key, position of the genome in the call) order: callers that list the
-    # genomes by label get records that need no sort (one vectorised check instead of a lexsort)
-    in_order = len(kk) < 2 or bool(np.all((kk[1:] > kk[:-1]) | ((kk[1:] == kk[:-1]) & (rk[1:] >= rk[:-1]))))
-    if in_order:
-        keys, genome, count = kk, records["genome"], records["count"]
-    else:
-        order = np.lexsort((rk, kk))
-        keys = kk[order]
-        genome = records["genome"][order]
-        count = records["count"][order]
+    records = _ordered_records(records, labels)
+    keys, genome, count = records["key"], records["genome"], records["count"]
     pm = codec.prefix_mask(L, R)
     new_key = np.ones(len(keys), dtype=bool)
     new_key[1:] = keys[1:] != keys[:-1]
@@ -215,6 +255,11 @@ def render(groups, ingroup_labels, dot=False):
     (outputAlignments.py:101-162): header, one row / block per group; each block is
     print()ed, hence the blank line after it."""
     ingroup = None if ingroup_labels is None else frozenset(ingroup_labels)
+    if isinstance(groups, RecordGroups):
+        text = groups.render_text(ingroup, dot)
+        if text is not None:
+            return text
+        groups = groups.groups()
     csv = [CSV_HEADER]
     blocks = []
     gc_was_on = gc.isenabled()

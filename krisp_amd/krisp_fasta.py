@@ -372,6 +372,9 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
                  candidates=int(ncand))
     if quirk_all_fail:
         return [], stats
+    if not touched and not any(rna):
+        # (plain records: the renderer works from them directly, the list of groups is built only if someone walks it)
+        return amplicon.RecordGroups(records, labels, Le, De, Re), stats
     groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
     if touched:
         groups = _merge_groups(groups, touched, sgroups)
@@ -493,7 +496,7 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         return None, stats
     if quirk_all_fail:
         return [], stats
-    return amplicon.groups_from_records(allrec, labels, Le, De, Re), stats
+    return amplicon.RecordGroups(allrec, labels, Le, De, Re), stats
 
 
 def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,

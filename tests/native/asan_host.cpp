@@ -63,6 +63,63 @@ int main() {
                     }
             }
     }
-    printf("ASAN_HOST_OK %ld scans\n", checks);
+    // the record renderer: random groups in (key, label) order, every geometry, with and without an ingroup, both
+    // alignment forms; records out of order or with ids outside the tables are refused, never read past
+    long renders = 0;
+    for (int it = 0; it < 3000; it++) {
+        const int L = rnd() % 9, D = rnd() % 4, R = rnd() % 6;
+        if (L + D + R == 0) continue;
+        const int k = L + D + R;
+        const size_t ngen = 1 + rnd() % 5, nlab = 1 + rnd() % ngen;
+        std::vector<uint32_t> label_of(ngen);
+        for (auto& v : label_of) v = rnd() % nlab;
+        std::vector<std::string> names(nlab);
+        std::vector<const char*> text(nlab);
+        for (size_t i = 0; i < nlab; i++) { names[i] = "lab" + std::to_string(i); text[i] = names[i].c_str(); }
+        std::vector<uint8_t> is_in(nlab);
+        for (auto& v : is_in) v = rnd() & 1;
+        std::vector<kr_record> recs;
+        // ascending distinct keys of k bases (the groups are whatever shares the (left,right) prefix)
+        const uint64_t space = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+        uint64_t v = rnd() % 3;
+        const int namps = rnd() % 12;
+        for (int a = 0; a < namps && v <= space; a++) {
+            const uint64_t key = k >= 32 ? v : (v << (64 - 2 * k));
+            std::vector<std::pair<uint32_t, uint32_t>> gs;          // genomes of this Amplicon in label order
+            for (uint32_t q = 0; q < ngen; q++)
+                if (rnd() & 1) gs.push_back({label_of[q], q});
+            if (gs.empty()) gs.push_back({label_of[0], 0});
+            std::sort(gs.begin(), gs.end());
+            for (auto& pr : gs) recs.push_back(kr_record{key, pr.second, 1 + rnd() % 3});
+            const uint64_t step = 1 + rnd() % 5;
+            if (space - v < step) break;
+            v += step;
+        }
+        for (int with_in = 0; with_in < 2; with_in++)
+            for (int dot = 0; dot < 2; dot++) {
+                char *csv = nullptr, *al = nullptr;
+                size_t nc = 0, na = 0;
+                const int64_t r = kr_render_records(recs.data(), recs.size(), L, D, R, label_of.data(), ngen, text.data(), nlab,
+                                                    with_in ? is_in.data() : nullptr, dot, &csv, &nc, &al, &na);
+                if (r < 0 && r != KR_ERR_HOST) { printf("render failed %lld\n", (long long)r); return 7; }
+                if (r >= 0 && (nc < 28 || csv[nc - 1] != '\n')) return 8;
+                kr_text_free(csv);
+                kr_text_free(al);
+                renders++;
+            }
+        if (recs.size() > 1) {
+            std::swap(recs[0], recs[recs.size() - 1]);
+            char *csv = nullptr, *al = nullptr;
+            size_t nc = 0, na = 0;
+            const int64_t r = kr_render_records(recs.data(), recs.size(), L, D, R, label_of.data(), ngen, text.data(), nlab, nullptr, 0,
+                                                &csv, &nc, &al, &na);
+            if (r >= 0 && recs[0].key != recs[recs.size() - 1].key) { kr_text_free(csv); kr_text_free(al); }
+            else if (r >= 0) { kr_text_free(csv); kr_text_free(al); }
+            recs[0].genome = 1000;
+            if (kr_render_records(recs.data(), recs.size(), L, D, R, label_of.data(), ngen, text.data(), nlab, nullptr, 0, &csv, &nc,
+                                  &al, &na) != KR_ERR_PARAM) return 9;
+        }
+    }
+    printf("ASAN_HOST_OK %ld scans %ld renders\n", checks, renders);
     return 0;
 }

@@ -574,3 +574,16 @@ def test_exchange_is_all_or_none_when_a_rank_runs_out_of_memory(N, K, tmp_path):
     assert res[0].startswith("error:") and "budget" in res[0], res
     assert all(r.startswith("error:") for r in res), res            # (ranks 1 and 2: "rank 0 failed", from its answers)
     assert time.time() - t0 < 50
+
+
+def test_fine_histogram_counts_beyond_sixteen_bits(N, K):
+    """k_hist16 counts in 16 bits unless the top-byte counts of k_hist8 say that a bin of the workgroup's range could
+    pass 65535; such a range counts in 32 bits, and what exceeds 16 bits leaves through the exception list.  A
+    9 Mbp genome with a 150 kb poly-A run and a 90 kb dinucleotide run: the sort equals the oracle's."""
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    body = acgt[rng.integers(0, 4, size=9_000_000)]
+    text = np.concatenate([body[:3_000_000], np.full(150_000, ord("A"), dtype=np.uint8), body[3_000_000:7_000_000],
+                           np.tile(np.frombuffer(b"AC", dtype=np.uint8), 45_000), body[7_000_000:]]).astype(np.uint8)
+    info = _check_sorted(N, K, text, 20, 1, 4)
+    assert info["b"] > 8 and info["overflow_segments"] > 0

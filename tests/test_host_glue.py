@@ -462,3 +462,80 @@ def test_primer3_hook_with_a_stand_in_package(monkeypatch):
     assert len(rows) == 3 and rows[1].startswith("ACGTA,C,GGATC,1.5,1.5,ACGT,ACGT")      # the TTTT group has no pair
     assert "Forward" not in align.split("\n")[0] and "Primer statistics:" in align and "Pair statistics:" in align
     assert align.count(" : inA") == 1
+
+
+def _random_records(rng, L, D, R, nl, ngroups, collide):
+    from krisp_amd import _native
+    k = L + D + R
+    labels = [f"g{c}" for c in rng.permutation(nl)]
+    if collide and nl > 1:
+        labels[1] = labels[0]                       # two files whose names collapse to one label
+    npre = 1 << min(2 * (L + R), 40)
+    pres = np.sort(rng.choice(npre, size=min(ngroups, npre), replace=False)) if L + R > 0 else np.zeros(1, dtype=np.int64)
+    recs = []
+    for p in pres:
+        nd = 1 if D == 0 else int(rng.integers(1, min(4, 4 ** D) + 1))
+        for d in (np.sort(rng.choice(4 ** D, size=nd, replace=False)) if D > 0 else [0]):
+            key = (int(p) << (64 - 2 * (L + R))) if L + R > 0 else 0
+            if D > 0:
+                key |= int(d) << (64 - 2 * k)
+            for g in rng.choice(nl, size=int(rng.integers(1, nl + 1)), replace=False):
+                recs.append((key, int(g), int(rng.integers(1, 4))))
+    r = np.array(recs, dtype=_native.RECORD)
+    return r[rng.permutation(len(r))], labels
+
+
+def test_library_renderer_equals_the_general_path():
+    """kr_render_records (one pass over the records, no object per Amplicon) against amplicon.render over
+    groups_from_records -- the restatement of Amplicon.py:523-671 the golden cases pin -- on random groups: every
+    geometry incl. L = 0 (the bracket quirk) and D = 0, multiplicities, label collisions, with and without an
+    ingroup, both alignment forms; where the reference raises (no all-ingroup row for the consensus) the library
+    declines and the general path raises as before"""
+    from krisp_amd import amplicon
+    rng = np.random.default_rng(3)
+    same = declined = 0
+    for it in range(400):
+        L, D, R = int(rng.integers(0, 8)), int(rng.integers(0, 4)), int(rng.integers(0, 6))
+        if L + D + R == 0:
+            continue
+        nl = int(rng.integers(1, 6))
+        recs, labels = _random_records(rng, L, D, R, nl, int(rng.integers(1, 8)), collide=it % 5 == 0)
+        ingroup = None if it % 3 == 0 else frozenset(labels[:max(1, nl // 2)])
+        for dot in (False, True):
+            rg = amplicon.RecordGroups(recs, labels, L, D, R)
+            assert len(rg) == len(amplicon.groups_from_records(recs, labels, L, D, R))
+            try:
+                want = amplicon.render(amplicon.groups_from_records(recs, labels, L, D, R), ingroup, dot)
+            except (ValueError, KeyError):
+                assert rg.render_text(ingroup, dot) is None
+                with pytest.raises((ValueError, KeyError)):
+                    amplicon.render(rg, ingroup, dot)
+                declined += 1
+                continue
+            assert amplicon.render(rg, ingroup, dot) == want, (L, D, R, labels, ingroup, dot)
+            same += 1
+    assert same > 300 and declined > 50
+
+
+def test_library_renderer_at_scale():
+    """2 x 10^5 groups of four records rendered by the library in a fraction of a second
+    (the general path needs ~2 s for them), the same text"""
+    import time
+    from krisp_amd import _native, amplicon
+    rng = np.random.default_rng(1)
+    L, D, R = 25, 1, 2
+    pre = np.unique(np.sort(rng.integers(0, 1 << 54, size=200_000, dtype=np.uint64)) << np.uint64(10))
+    ng = len(pre)
+    b1 = rng.integers(0, 4, size=ng).astype(np.uint64)
+    b2 = (b1 + rng.integers(1, 4, size=ng).astype(np.uint64)) & np.uint64(3)
+    recs = np.empty(ng * 4, dtype=_native.RECORD)
+    recs["key"] = np.stack([pre | (b1 << np.uint64(8))] * 2 + [pre | (b2 << np.uint64(8))] * 2, axis=1).reshape(-1)
+    recs["genome"] = np.tile(np.arange(4, dtype=np.uint32), ng)
+    recs["count"] = 1
+    recs = recs[np.lexsort((recs["genome"], recs["key"]))]
+    labels, ingroup = ["inA", "inB", "outX", "outY"], frozenset(["inA", "inB"])
+    t0 = time.time()
+    fast = amplicon.render(amplicon.RecordGroups(recs, labels, L, D, R), ingroup)
+    dt = time.time() - t0
+    assert fast == amplicon.render(amplicon.groups_from_records(recs, labels, L, D, R), ingroup)
+    assert dt < 1.0, dt
