@@ -153,6 +153,9 @@ int     kr_comm_world(kr_ctx*);
 int     kr_comm_barrier(kr_ctx*);                               /* syncs the stream, then all ranks meet */
 /* vals[0..n) reduced over all ranks, n <= 8: op 0 = sum, 1 = max; the result on every rank */
 int     kr_comm_allreduce(kr_ctx*, double* vals, int n, int op);
+/* n bytes of every rank -> every rank: out[r * n .. (r + 1) * n) = rank r's (the same n on every rank); small side
+ * data of the flow (windows with IUPAC letters, krisp_fasta.py), not candidate lists */
+int     kr_comm_allgather(kr_ctx*, const void* mine, size_t n, void* out);
 /* candidates := those present on EVERY rank, masks OR-ed (filtered when apply_filter), on rank 0;
  * returns the count on rank 0, 0 elsewhere (the other ranks' sets are spent) */
 int64_t kr_cands_reduce(kr_ctx*, int apply_filter);

@@ -68,6 +68,7 @@ SYMBOLS = [
     ("kr_comm_world", _c.c_int, [_P]),
     ("kr_comm_barrier", _c.c_int, [_P]),
     ("kr_comm_allreduce", _c.c_int, [_P, _P, _c.c_int, _c.c_int]),
+    ("kr_comm_allgather", _c.c_int, [_P, _P, _c.c_size_t, _P]),
     ("kr_cands_reduce", _c.c_int64, [_P, _c.c_int]),
     ("kr_cands_bcast", _c.c_int64, [_P]),
     ("kr_records_gather", _c.c_int64, [_P]),
@@ -403,6 +404,23 @@ class Engine:
         v = np.asarray(values, dtype=np.float64).copy()
         self._check(self.lib.kr_comm_allreduce(self.ctx, _ptr(v), len(v), 1 if op == "max" else 0), "kr_comm_allreduce")
         return v
+
+    def comm_allgather(self, data):
+        """bytes of every rank (any length) -> list of bytes by rank"""
+        world = self.lib.kr_comm_world(self.ctx)
+        if world == 1:
+            return [bytes(data)]
+        n = int(self.comm_allreduce([float(len(data))], "max")[0]) + 8
+        mine = np.zeros(n, dtype=np.uint8)
+        mine[:8] = np.frombuffer(np.uint64(len(data)).tobytes(), dtype=np.uint8)
+        mine[8:8 + len(data)] = np.frombuffer(bytes(data), dtype=np.uint8)
+        out = np.empty(n * world, dtype=np.uint8)
+        self._check(self.lib.kr_comm_allgather(self.ctx, _ptr(mine), n, _ptr(out)), "kr_comm_allgather")
+        res = []
+        for r in range(world):
+            ln = int(np.frombuffer(out[r * n:r * n + 8].tobytes(), dtype=np.uint64)[0])
+            res.append(out[r * n + 8:r * n + 8 + ln].tobytes())
+        return res
 
     def cands_reduce(self, apply_filter):
         """tree reduction of every rank's candidates onto rank 0 (the count there, 0 elsewhere)"""

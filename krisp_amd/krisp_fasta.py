@@ -175,13 +175,22 @@ def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter):
     touched = {(l, r) for sp in specials for (l, d, r) in sp}
     if not touched:
         return touched, []
-    members = {}            # (left,right) -> {(left,diag,right) -> {genome index -> count}}
     pure = sorted({_prefix_key(l, r) for (l, r) in touched if _pure(l) and _pure(r)})
+    recs = None
     if pure:
         cands = np.zeros(len(pure), dtype=_native.CAND)
         cands["prefix"] = np.array(pure, dtype=np.uint64)
         eng.load_cands(cands)
         recs = eng.collect(ids)
+    return touched, _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter)
+
+
+def _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter):
+    """the groups IUPAC windows touch, from the device records of their ACGT members (`recs`: of one context, or
+    gathered from every rank of a multi-GPU run) and the IUPAC members themselves (specials[g] of genome ids[g])"""
+    L, D, R = geo
+    members = {}            # (left,right) -> {(left,diag,right) -> {genome index -> count}}
+    if recs is not None:
         for rec in recs:
             l, d, r = codec.key_columns(rec["key"], L, D, R)
             gi = ids.index(int(rec["genome"]))
@@ -209,7 +218,7 @@ def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter):
         if do_filter and not amplicon.ingroup_unique_columns(group, ingroup):
             continue
         groups.append(group)
-    return touched, groups
+    return groups
 
 
 def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, geo, ingroup, do_filter):
@@ -435,12 +444,25 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         loaded = together(lambda: [fasta.ingest(order[g], k, omit_soft) for g in mine])
         kinds = eng.comm_allreduce([1.0 if any(sp for _, _, sp in loaded) else 0.0,
                                     1.0 if any(r for _, r, _ in loaded) else 0.0,
-                                    float(max(len(b) for b, _, _ in loaded))], "max")
+                                    float(max(len(b) for b, _, _ in loaded)),
+                                    1.0 if any(not r for _, r, _ in loaded) else 0.0], "max")
+        if kinds[1] and kinds[3]:
+            raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+        all_rna = bool(kinds[1])
+        if kinds[0] and wide:
+            raise fasta.IupacWindowsUnsupported("IUPAC ambiguity letters inside long amplicons: run on one GPU (their "
+                                                "groups are rebuilt through probe genomes there)")
+        # windows with IUPAC letters (kept by the reference, kstream.py:11-18; the device alphabet cannot carry them):
+        # every rank learns all of them -- they are rare --, the groups they touch are rebuilt on rank 0 from the
+        # ranks' device look-ups of the ACGT members (below), as find_regions does on one GPU
+        specials_all = None
         if kinds[0]:
-            raise fasta.IupacWindowsUnsupported("IUPAC ambiguity letters: run on one GPU (their groups need "
-                                                "look-ups across all genomes)")
-        if kinds[1]:
-            raise MixedAlphabet("RNA input: run on one GPU")
+            import pickle
+            mine_sp = {g: [codec.split_window(w, Le, De, Re) for w in sp] for g, (_, _, sp) in zip(mine, loaded)}
+            specials_all = [[] for _ in order]
+            for blob in eng.comm_allgather(pickle.dumps(mine_sp)):
+                for g, sp in pickle.loads(blob).items():
+                    specials_all[g] = sp
         stats = {"read_s": time.time() - t0}
         t1 = time.time()
         quirk_all_fail = do_filter and De == 0
@@ -474,7 +496,8 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
             for g in sorted(set(hits["genome"].tolist())):
                 if texts[g] is None:
                     texts[g] = fasta.ingest(order[g], k, omit_soft)[0]
-            return _groups_from_hits(hits, texts, labels, Le, De, Re), stats
+            wg = _groups_from_hits(hits, texts, labels, Le, De, Re)
+            return (_to_rna(wg) if all_rna else wg), stats
 
         def device_part():
             eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=int(kinds[2]))
@@ -490,13 +513,41 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         nrec = together(lambda: 0 if quirk_all_fail else eng.collect(mine, fetch=False))
         total = eng.records_gather() if not quirk_all_fail else 0
         allrec = eng.fetch_records(total) if rank == 0 and not quirk_all_fail else None
+        sprec, touched = None, set()
+        if specials_all is not None and not quirk_all_fail:
+            # the ACGT members of every (left,right) group an IUPAC window touches: each rank looks them up in ITS
+            # genomes (the touched prefixes as a candidate list), rank 0 gets all the records
+            touched = {(l, r) for sp in specials_all for (l, d, r) in sp}
+            pure = sorted({_prefix_key(l, r) for (l, r) in touched if _pure(l) and _pure(r)})
+
+            def special_lookups():
+                if not pure:
+                    return 0
+                cands = np.zeros(len(pure), dtype=_native.CAND)
+                cands["prefix"] = np.array(pure, dtype=np.uint64)
+                eng.load_cands(cands)
+                return eng.collect(mine, fetch=False)
+
+            together(special_lookups)
+            if pure:
+                tot2 = eng.records_gather()
+                sprec = eng.fetch_records(tot2) if rank == 0 else None
         eng.comm_barrier()
-        stats.update(device_s=time.time() - t1, kmers=int(counts), candidates=int(max(ncand, 0)), records=int(nrec))
+        stats.update(device_s=time.time() - t1, kmers=int(counts) + (sum(len(sp) for sp in specials_all) if specials_all else 0),
+                     candidates=int(max(ncand, 0)), records=int(nrec))
     if rank != 0:
         return None, stats
     if quirk_all_fail:
         return [], stats
-    return amplicon.RecordGroups(allrec, labels, Le, De, Re), stats
+    finish = _to_rna if all_rna else (lambda groups: groups)
+    if not touched and not all_rna:
+        return amplicon.RecordGroups(allrec, labels, Le, De, Re), stats
+    groups = amplicon.groups_from_records(allrec, labels, Le, De, Re)
+    if touched:
+        sgroups = _special_groups_from(sprec, list(range(len(order))), labels, specials_all, (Le, De, Re),
+                                       ingroup_labels, do_filter)
+        groups = _merge_groups(groups, touched, sgroups)
+    return finish(groups), stats
 
 
 def find_regions_distributed(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=False,

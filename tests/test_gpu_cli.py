@@ -558,6 +558,45 @@ def test_random_genomes_with_iupac_letters_match_the_text_oracle(seed, tmp_path)
     assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_iupac_letters_and_rna_over_several_ranks(seed, tmp_path):
+    """The multi-GPU flow keeps what the one-GPU flow keeps: windows with IUPAC ambiguity letters (every rank
+    learns all of them -- kr_comm_allgather --, the ACGT members of the groups they touch are looked up by every
+    rank in its own genomes and gathered on rank 0) and RNA input (U in, U out).  Three or four genomes over two
+    or three ranks sharing the GPU, against the text oracle's stages."""
+    import random
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    from oracle import krisp_oracle as O
+    rng = random.Random(7000 + seed)
+    L, D, R = rng.choice([(4, 1, 2), (3, 2, 3), (5, 0, 4), (6, 1, 3)])
+    rna = seed % 3 == 2
+    n_in, n_out = 2, rng.randint(1, 2)
+    anc = "".join(rng.choice("ACGT") for _ in range(rng.randint(120, 400)))
+    ing, outg = [], []
+    for gi in range(n_in + n_out):
+        s = list(anc)
+        for _ in range(rng.randint(0, 6)):
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        for _ in range(rng.randint(1, 5)):
+            s[rng.randrange(len(s))] = rng.choice("RYKMSWryn")
+        text = "".join(s)
+        if rna:
+            text = text.replace("T", "U").replace("t", "u")
+        p = tmp_path / f"{'in' if gi < n_in else 'out'}{gi}.fa"
+        p.write_text(">r\n" + text + "\n")
+        (ing if gi < n_in else outg).append(str(p))
+    k = L + D + R
+    sf = [(f"{O.basename(f)}.{k}mers", O.extract_sorted_kmers(f, L, R, k, False)) for f in ing + outg]
+    merged = O.merge_tree(sf)
+    expect = O.filter_lines(merged, [O.simplename(f) for f in ing]) if D > 0 else merged
+    one, _ = KF.find_regions(ing, outg, L, R, k)
+    assert sorted(amplicon.merged_lines(one)) == sorted(expect)
+    devices = [0] * (2 if seed % 2 == 0 else 3)
+    groups, _ = KF.find_regions_multi_device(ing, outg, L, R, k, devices)
+    assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
+
+
 @pytest.mark.parametrize("name,texts,n_in", [
     ("shorter_than_k", [">a\nACGTACGTAC\n", ">b\nACGTACGTACGTTTT\n"], 1),
     ("all_N", [">a\n" + "N" * 300 + "\n", ">b\n" + "ACGT" * 80 + "\n"], 1),
