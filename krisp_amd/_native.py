@@ -30,12 +30,14 @@ STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
           "fallback", "intersect", "compact", "collect", "merge", "locate"]
 # stage -> the kernel(s) it times (names as rocprofv3 prints them)
-STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8", "reduce8": "k_reduce8", "scatter1": "k_scatter1p",
+STAGE_KERNELS = {"pack": "k_pack", "hist8": "k_hist8 (wide path: k_hist8w, slices: k_hist8k)", "reduce8": "k_reduce8a+k_reduce8b",
+                 "scatter1": "k_scatter1p (wide path: k_scatter1w, slices: k_scatter1kp)",
                  "hist2": "k_hist16 (or k_hist2)", "scan2": "k_hist16_off (or k_scan2)", "scatter2": "k_scatter2",
-                 "chunks": "k_chunk_bounds+k_chunk_desc", "localsort": "k_localsort2",
-                 "fallback": "k_bitonic_stage", "intersect": "k_intersect", "compact": "k_scan+k_gather_cands",
-                 "collect": "k_collect", "merge": "k_cands_flag+k_scan+k_cands_compact",
-                 "locate": "k_wide_locate"}
+                 "chunks": "k_chunk_table", "localsort": "k_localsort2",
+                 "fallback": "k_seg_merge", "intersect": "k_intersect3 (+ k_intersect for oversized items)",
+                 "compact": "k_scan+k_publish_reset+k_gather_items",
+                 "collect": "k_collect_count+k_tile_sums+k_scan+k_tile_apply+k_publish+k_collect_emit",
+                 "merge": "k_cands_flag+k_scan+k_cands_compact", "locate": "k_wide_locate"}
 
 # every symbol include/krisp_hip.h declares: (name, restype, argtypes)
 _c = ctypes

@@ -1,18 +1,18 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of one round on the GPU box (run through gpurun from the
-# repo root):  bash tools/profile_round.sh r01
+# repo root):  bash tools/profile_round.sh r03
 #   profiles/<round>/bench.json          the bench line (default workload = BASELINE configs[1])
 #   profiles/<round>/kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
 #   profiles/traffic.json                HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE)
 # Everything is written under gpurun_out/<round>/ (merged back by gpurun); copy into profiles/ afterwards.
 set -e
-R=${1:-r01}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-tail -1 "$OUT/bench.json"
+tail -1 "$OUT/bench.json" | head -c 1500; echo
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-stage-timers > "$OUT/pmc_fetch.log" 2>&1
