@@ -226,6 +226,19 @@ int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines,
  * is_fasta, read us, inflate us, parse us, gzip members | used_libdeflate << 32.  Returns the
  * number of bytes; .bz2 files return KR_ERR_HOST (the host layer inflates them). */
 int64_t kr_ingest_file(const char* path, uint8_t** bases, int64_t* stats);
+/* The same ingest with the PARSE on the device (the host reads and inflates only):
+ *   kr_read_file            the file's text in pinned host memory (free with kr_host_free); stats[8]: [3] = 1 when the
+ *                           text wants universal newlines (a plain file), [4] read us, [5] inflate us, [6] copy us,
+ *                           [7] gzip members | used_libdeflate << 32.  Returns the number of bytes; .bz2: KR_ERR_HOST.
+ *   kr_genome_upload_text   text -> genome `id`'s upload buffer, parsed on the device (csrc/k_text.inc) with exactly
+ *                           kr_fasta_to_bases' result (the tests compare them byte for byte), then as
+ *                           kr_genome_upload.  stats[4] = records, characters outside ACGTNacgtn, is_rna, is_fasta.
+ *                           Returns the number of bases (separators included).
+ *   kr_genome_fetch_bases   an uploaded genome's bases back to the host (the IUPAC side channel, text cutting) */
+int64_t kr_read_file(const char* path, uint8_t** text, int64_t* stats);
+int64_t kr_genome_upload_text(kr_ctx*, int id, const uint8_t* text, size_t n, int universal_newlines, int one_shot,
+                              int64_t* stats);
+int64_t kr_genome_fetch_bases(kr_ctx*, int id, uint8_t* out, size_t cap);
 void    kr_host_free(void* p);
 
 /* Host-side (no GPU involved): the side channel of SURVEY 8(b) -- the windows the device's 2-bit

@@ -81,6 +81,9 @@ SYMBOLS = [
     ("kr_wide_fetch", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_fasta_to_bases", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     ("kr_ingest_file", _c.c_int64, [_c.c_char_p, _P, _P]),
+    ("kr_read_file", _c.c_int64, [_c.c_char_p, _P, _P]),
+    ("kr_genome_upload_text", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t, _c.c_int, _c.c_int, _P]),
+    ("kr_genome_fetch_bases", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_host_free", None, [_P]),
     ("kr_scan_special", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     ("kr_set_option", _c.c_int, [_P, _c.c_int, _c.c_int64]),
@@ -189,6 +192,30 @@ def ingest_file(path):
     return arr, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3]), timings
 
 
+def read_file(path):
+    """file -> (its text as a uint8 view of library-owned, pinned memory; universal_newlines; timings) through
+    kr_read_file: read + inflate inside the library, GIL released; the parse is left to the device
+    (Engine.upload_text).  None for files the library leaves to the host layer (.bz2)."""
+    lib = load()
+    out = ctypes.c_void_p(0)
+    stats = np.zeros(8, dtype=np.int64)
+    n = lib.kr_read_file(os.fsencode(path), ctypes.byref(out), _ptr(stats))
+    if n == ERR_HOST:
+        return None
+    if n < 0:
+        msg = lib.kr_last_error(None).decode()
+        if "cannot open" in msg:
+            raise FileNotFoundError(msg)
+        raise KrispHipError(f"kr_read_file({path}): [{n}] {msg}")
+    block = _HostBlock(lib, out.value)
+    raw = (ctypes.c_uint8 * max(int(n), 1)).from_address(out.value)
+    raw._owner = block
+    arr = np.frombuffer(raw, dtype=np.uint8)[:n]
+    timings = dict(read_s=stats[4] / 1e6, inflate_s=stats[5] / 1e6, copy_s=stats[6] / 1e6,
+                   members=int(stats[7] & 0xFFFFFFFF), libdeflate=bool(stats[7] >> 32))
+    return arr, bool(stats[3]), timings
+
+
 def render_records(records, label_of, label_text, label_in, L, D, R, dot=False):
     """kr_render_records: (csv_text, alignment_text, number of groups), or None when the library leaves a group to
     the general path.  records: RECORD array ordered by (key, label id); label_of: genome id -> label id;
@@ -279,6 +306,20 @@ class Engine:
         return rc
 
     # ---- configuration
+    def upload_text(self, gid, text, universal_newlines, one_shot=True):
+        """file text -> genome gid, parsed on the device with the reference reader's semantics (kr_genome_upload_text).
+        Returns (bases, records, special characters, rna, fasta)."""
+        t = np.ascontiguousarray(text, dtype=np.uint8)
+        stats = np.zeros(4, dtype=np.int64)
+        n = self._check(self.lib.kr_genome_upload_text(self.ctx, gid, _ptr(t), len(t), 1 if universal_newlines else 0,
+                                                       1 if one_shot else 0, _ptr(stats)), "kr_genome_upload_text")
+        return n, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
+
+    def fetch_bases(self, gid, n):
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        m = self._check(self.lib.kr_genome_fetch_bases(self.ctx, gid, _ptr(out), n), "kr_genome_fetch_bases")
+        return out[:m]
+
     def set_option(self, option, value):
         """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ISECT_KERNEL, OPT_WIDE_SLOTS); before set_params"""
         self._check(self.lib.kr_set_option(self.ctx, option, int(value)), "kr_set_option")

@@ -94,6 +94,37 @@ def load_bases(filename):
     return bases, bool(rna), nspecial
 
 
+def read_text(filename):
+    """file -> (its text, universal_newlines): read + inflate only -- inside the library into pinned memory
+    (kr_read_file) where it takes the file, else through Python's gzip / bz2.  The parse is left to the device
+    (ingest_on_device)."""
+    from . import _native
+    ext = os.path.splitext(filename)[1]
+    if ext != ".bz2":
+        got = _native.read_file(filename)
+        if got is not None:
+            text, universal, timings = got
+            LAST_TIMINGS[os.fspath(filename)] = dict(timings, parse_s=0.0)
+            return text, universal
+    if ext == ".bz2":
+        with bz2.open(filename, "rb") as f:
+            return np.frombuffer(f.read(), dtype=np.uint8), False
+    if ext == ".gz":
+        with gzip.open(filename, "rb") as f:
+            return np.frombuffer(f.read(), dtype=np.uint8), False
+    with open(filename, "rb") as f:
+        return np.frombuffer(f.read(), dtype=np.uint8), True
+
+
+def ingest_on_device(eng, gid, text, universal, k, omit_soft):
+    """text of a sequence file -> genome gid of `eng`, parsed on the device with the reference reader's semantics
+    (kr_genome_upload_text; the host never sees the bases unless the genome holds characters outside ACGTNacgtn:
+    then they come back for the side channel of ingest()).  Returns (bases on the device, is_rna, IUPAC k-mers)."""
+    n, _nrec, nspecial, rna, _fasta = eng.upload_text(gid, text, universal, one_shot=True)
+    special = scan_special(eng.fetch_bases(gid, n), k, omit_soft) if nspecial else []
+    return n, bool(rna), special
+
+
 def ingest(source, k, omit_soft):
     """file name or iterable of sequence strings -> (upload buffer, is_rna, IUPAC k-mers).
     Files go through the library's one-pass parser; characters the device cannot carry are

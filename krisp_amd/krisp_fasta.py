@@ -280,6 +280,59 @@ def _merge_groups(device_groups, touched, special_groups):
     return out
 
 
+def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
+                                workers, t0):
+    """find_regions' packed path with the reader on the device: the host threads read and inflate, the main thread
+    hands each text to the GPU (parse -> sort) as it arrives.  Same results as the host-parse flow (the device reader
+    equals kr_fasta_to_bases byte for byte: tests/test_gpu_kernels.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _native
+    Le, De, Re = geo
+    if len(files) == 1:
+        labels = ["merged_file"]
+    else:
+        labels = [simplename(f) for f in files]
+    ingroup_labels = frozenset(simplename(f) for f in ingroup_files)
+    flags = [lab in ingroup_labels for lab in labels]
+    with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device) as eng:
+        futures = [pool.submit(fasta.read_text, f) for f in files]
+        first = [fu.result() for fu in futures]            # (the texts' sizes bound the genomes': needed for the sort plan)
+        read_s = time.time() - t0
+        t1 = time.time()
+        eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(max(len(t) for t, _ in first), 1))
+        rna, specials = [], []
+        for i, (text, universal) in enumerate(first):
+            _n, r, sp = fasta.ingest_on_device(eng, i, text, universal, k, omit_soft)
+            rna.append(r)
+            specials.append([codec.split_window(w, Le, De, Re) for w in sp])
+            eng.sort(i)
+        del first
+        if any(rna) and not all(rna):
+            raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+        finish = _to_rna if all(rna) else (lambda groups: groups)
+        ids = list(range(len(files)))
+        ncand = eng.intersect(ids, flags, apply_filter=do_filter and not quirk_all_fail)
+        counts = [eng.count(i) for i in ids]
+        if verbose:
+            for f, cnt in zip(files, counts):
+                print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)
+        by_label = sorted(ids, key=lambda i: labels[i])
+        records = eng.collect(by_label) if (ncand and not quirk_all_fail) else np.empty(0, dtype=_native.RECORD)
+        touched, sgroups = set(), []
+        if any(specials) and not quirk_all_fail:
+            touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels, do_filter)
+    stats = {"read_s": read_s, "device_s": time.time() - t1,
+             "kmers": int(sum(counts)) + sum(len(sp) for sp in specials), "candidates": int(ncand)}
+    if quirk_all_fail:
+        return [], stats
+    if not touched and not any(rna):
+        return amplicon.RecordGroups(records, labels, Le, De, Re), stats
+    groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
+    if touched:
+        groups = _merge_groups(groups, touched, sgroups)
+    return finish(groups), stats
+
+
 # ----------------------------------------------------------------------------
 # the fused device flow used by main()
 # ----------------------------------------------------------------------------
@@ -307,9 +360,15 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     elif not wide:
         _check_geometry(Le, De, Re)
     t0 = time.time()
-    # ingest: files are read, inflated and parsed concurrently (the parser releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, min(len(files), os.cpu_count() or 1, 16))) as pool:
+    workers = max(1, min(len(files), os.cpu_count() or 1, 16))
+    if not wide and os.environ.get("KRISP_HOST_PARSE") != "1":
+        # files are read and inflated concurrently on the host (the library releases the GIL); the PARSE runs on the
+        # device, genome by genome as the texts arrive (fasta.ingest_on_device), each followed at once by its sort
+        return _find_regions_device_ingest(files, ingroup_files, L, R, k, (Le, De, Re), omit_soft, device, verbose,
+                                           do_filter, quirk_all_fail, workers, t0)
+    # ingest: files are read, inflated and parsed concurrently (the parser releases the GIL)
+    with ThreadPoolExecutor(max_workers=workers) as pool:
         loaded = list(pool.map(lambda f: fasta.ingest(f, k, omit_soft), files))
     texts = [b for b, _, _ in loaded]
     specials = [[codec.split_window(w, Le, De, Re) for w in sp] for _, _, sp in loaded]

@@ -587,3 +587,63 @@ def test_fine_histogram_counts_beyond_sixteen_bits(N, K):
                            np.tile(np.frombuffer(b"AC", dtype=np.uint8), 45_000), body[7_000_000:]]).astype(np.uint8)
     info = _check_sorted(N, K, text, 20, 1, 4)
     assert info["b"] > 8 and info["overflow_segments"] > 0
+
+
+def test_device_reader_equals_the_host_parser(N, tmp_path):
+    """kr_genome_upload_text (the reference reader on the device, csrc/k_text.inc) against kr_fasta_to_bases, the host
+    parser pinned to the reference's reader by tests/test_host_glue.py: the reader vectors of the golden files, the
+    test_data genomes, 600 adversarial random texts (headers, blank and indented lines, every newline flavour, '>'
+    inside lines, RNA, non-FASTA inputs, first-line consumption, texts ending with and without a newline) and two
+    shapes of large input (80-column lines; records of one long line) -- the same bytes, records, special-character
+    count, RNA and FASTA verdicts."""
+    import gzip
+    import json
+    import os
+    import random
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    texts = []
+    for c in json.load(open(os.path.join(golden, "kstream_cases.json"))):
+        if c["file_text"] is not None:
+            texts.append((c["file_text"].encode(), not c["fname"].endswith(".gz")))
+    for fn in sorted(os.listdir(os.path.join(golden, "c1"))):
+        texts.append((gzip.open(os.path.join(golden, "c1", fn), "rb").read(), False))
+    rng = random.Random(5)
+    for i in range(600):
+        pieces = []
+        for _ in range(rng.randint(0, 12)):
+            kind = rng.random()
+            if kind < 0.25:
+                pieces.append(">" + "".join(rng.choice("abc >x") for _ in range(rng.randint(0, 6))))
+            elif kind < 0.35:
+                pieces.append(rng.choice(["", " ", "\t"]))
+            else:
+                pieces.append(rng.choice(["", " ", "  "]) +
+                              "".join(rng.choice("ACGTacgtNnUuRY>x ") for _ in range(rng.randint(0, 30))) +
+                              rng.choice(["", " ", "\t "]))
+        nl = rng.choice(["\n", "\r\n", "\r", "\n"])
+        text = (nl.join(pieces) + rng.choice(["", nl, nl + nl])).encode()
+        texts.append((text, i % 2 == 0))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    nprng = np.random.default_rng(3)
+    body = acgt[nprng.integers(0, 4, size=3_000_000)].tobytes()
+    wrapped = b">chr1 some text\n" + b"\n".join(body[i:i + 80] for i in range(0, 1_500_000, 80)) + b"\n>chr2\n" + \
+        b"\n".join(body[i:i + 60] for i in range(1_500_000, 3_000_000, 60)) + b"\n"
+    texts.append((wrapped, False))
+    texts.append((b">a\n" + body[:2_000_000] + b"\n>b\r\n" + body[2_000_000:].replace(b"T", b"U") + b"\n", True))
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=3_100_000)
+        for i, (text, universal) in enumerate(texts):
+            for one_shot in (True, False):
+                want, wrec, wspecial, wrna, wfasta = N.fasta_to_bases(text, universal, one_shot)
+                n, rec, special, rna, fa = e.upload_text(0, np.frombuffer(text, dtype=np.uint8), universal, one_shot)
+                got = e.fetch_bases(0, n)
+                assert n == len(want) and got.tobytes() == want.tobytes(), (i, one_shot, text[:200])
+                assert (rec, special, rna, fa) == (wrec, wspecial, wrna, wfasta), (i, one_shot, text[:200])
+        # ... and what was parsed there sorts like what was parsed here
+        text, universal = texts[-2]
+        want = N.fasta_to_bases(text, universal, True)[0]
+        n = e.upload_text(1, np.frombuffer(text, dtype=np.uint8), universal)[0]
+        e.sort(1)
+        e.upload(2, want)
+        e.sort(2)
+        assert np.array_equal(e.keys(1), e.keys(2))
