@@ -156,10 +156,11 @@ def cpu_baseline(config, L, D, R, length, full_length, per_gpu):
         length = int(min(full_length, max(1_000_000, 15.0 / (per_gpu * per_mbp) * 1e6)))
         length -= length % 1_000_000
     dt, n = run(make_genomes(config, 0, 1, per_gpu, length), replicas)
-    out = {"value": n / dt, "unit": "k-mers/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+    out = {"value": n / dt, "unit": "k-mers/s", "cores": cores, "cores_on_host": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
            "sample": f"{replicas} side-by-side replica(s) of {per_gpu} x {length / 1e6:g} Mbp genomes of the same "
                      f"generator, {L}/{D}/{R}, {n} k-mers in {dt:.1f} s (oracle/kmer_oracle.c: generate + LSD radix "
-                     f"sort, one thread per genome; n-way intersect + filter + collect on one thread per replica)",
+                     f"sort, one thread per genome; n-way intersect + filter + collect on one thread per replica); {cores} of the host's "
+                     f"{os.cpu_count()} cores (the one-GPU share of the box)",
            "reference_python": REFERENCE_PYTHON}
     # BASELINE configs[0]: the reference's test data through the same oracle (file text -> records)
     try:

@@ -381,23 +381,9 @@ class Engine:
     def intersect(self, gids, is_ingroup, apply_filter=True):
         ids = np.asarray(gids, dtype=np.int32)
         flags = np.asarray([1 if f else 0 for f in is_ingroup], dtype=np.uint8)
-        m = self.MAX_GENOMES_PER_CALL
-        if len(ids) <= m:
-            return self._check(self.lib.kr_intersect(self.ctx, _ptr(ids), len(ids), _ptr(flags),
-                                                     1 if apply_filter else 0), "kr_intersect")
-        # cascade: batches of MAXG genomes, candidate lists merged on the device (masks OR-ed);
-        # the filter needs every genome's masks, so it runs once at the end
-        prev = None
-        for o in range(0, len(ids), m):
-            bi, bf = np.ascontiguousarray(ids[o:o + m]), np.ascontiguousarray(flags[o:o + m])
-            n = self._check(self.lib.kr_intersect(self.ctx, _ptr(bi), len(bi), _ptr(bf), 0), "kr_intersect")
-            if prev is not None:
-                n = self.merge_cands(prev, apply_filter=False)
-            if o + m < len(ids):
-                prev = self.cands().copy()
-        if apply_filter:
-            n = self.merge_cands(None, apply_filter=True)
-        return n
+        # (more than 32 genomes: the library intersects them in batches and keeps the running list on the device)
+        return self._check(self.lib.kr_intersect(self.ctx, _ptr(ids), len(ids), _ptr(flags),
+                                                 1 if apply_filter else 0), "kr_intersect")
 
     def cands(self):
         n = self._check(self.lib.kr_cands_count(self.ctx), "kr_cands_count")
