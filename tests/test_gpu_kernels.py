@@ -216,8 +216,7 @@ def test_options_are_checked(N, monkeypatch):
 
 def test_hard_limits_fail_loudly(N):
     """the library's caps are errors with a message, never silent truncation: genomes of 2^32 bases,
-    more keys in one sort unit than a buffer descriptor spans, more genomes than one intersect call
-    takes, geometries beyond the key and mask formats"""
+    more keys in one sort unit than a buffer descriptor spans, geometries beyond the key and mask formats"""
     with N.Engine() as e:
         with pytest.raises(N.KrispHipError, match="2\\^32"):
             e.set_params(25, 1, 2, max_bases=(1 << 32) - 10)
@@ -237,9 +236,9 @@ def test_hard_limits_fail_loudly(N):
             e.add(i, text)
         ids = np.arange(33, dtype=np.int32)
         flags = np.ones(33, dtype=np.uint8)
-        rc = e.lib.kr_intersect(e.ctx, N._ptr(ids), 33, N._ptr(flags), 0)       # (Engine.intersect cascades instead)
-        assert rc == -2 and b"at most 32 genomes" in e.lib.kr_last_error(e.ctx)
-        assert e.intersect(list(range(33)), [True] * 33, apply_filter=False) > 0
+        # (more than 32 genomes per call: batches inside the library since round 3, the running list stays on the device)
+        rc = e.lib.kr_intersect(e.ctx, N._ptr(ids), 33, N._ptr(flags), 0)
+        assert rc > 0 and e.intersect(list(range(33)), [True] * 33, apply_filter=False) == rc
     with N.Engine() as e:
         with pytest.raises(N.KrispHipError):
             e.set_params_wide(65, 10, 20, max_bases=1000)        # flank > KR_WIDE_MAX_FLANK
@@ -648,3 +647,37 @@ def test_device_reader_equals_the_host_parser(N, tmp_path):
         e.upload(2, want)
         e.sort(2)
         assert np.array_equal(e.keys(1), e.keys(2))
+
+
+def test_intersect_right_behind_sorts_that_need_the_merge_fallback(N, K):
+    """kr_intersect does not wait for the sorts: it looks at what they left open after its own synchronisation.
+    Genomes with satellites (buckets too large for the LDS sort) are sorted and intersected WITHOUT asking for their
+    counts in between: the oversized buckets are repaired then and the intersection is redone -- same candidates and
+    records as the oracle's."""
+    rng = np.random.default_rng(23)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = rng.integers(0, 4, size=300_000)
+    unit = rng.integers(0, 4, size=29)
+    texts = []
+    for g in range(3):
+        a = base.copy()
+        m = rng.random(len(a)) < 0.004
+        a[m] = (a[m] + 1) % 4
+        texts.append(np.concatenate([acgt[a[:100_000]], acgt[np.tile(unit, 3000 + 10 * g)], acgt[a[100_000:]]]).astype(np.uint8))
+    L, D, R = 14, 1, 5
+    flags = [1, 1, 0]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
+    with N.Engine() as e:
+        e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
+        for i, t in enumerate(texts):
+            e.upload(i, t)
+            e.sort(i)                                   # (no count, no keys: nothing makes the host look at the sort)
+        for filt in (False, True):
+            want = K.intersect(want_keys, flags, L, D, R, apply_filter=filt)
+            assert e.intersect([0, 1, 2], flags, apply_filter=filt) == len(want)
+            got = e.cands()
+            for f in ("prefix", "in_mask", "out_mask"):
+                assert np.array_equal(got[f], want[f]), (f, filt)
+        assert e.debug_info()["overflow_segments"] > 0
+        for i in range(3):
+            assert np.array_equal(e.keys(i), want_keys[i])
