@@ -462,6 +462,7 @@ def test_wide_right_flank_through_the_left_dictionary(N, geo, monkeypatch):
     flags = [f for _, f, _ in fam]
     ids = list(range(len(fam)))
     texts, names = [t for _, _, t in fam], [nm for nm, _, _ in fam]
+    monkeypatch.delenv("KR_WIDE_ORDERED", raising=False)      # (the ordered generator never shares the spectrum)
 
     def run(share):
         monkeypatch.setenv("KR_WIDE_SHARE", "1" if share else "0")
