@@ -275,8 +275,9 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
        KR_OPT_PLACE_TRIES = 7,       /* 1 .. 16 (default 8): candidate allocations of the pass-1 output buffer (>= 256 MB), each timed under
                                         pass 1's write pattern, the fastest kept: physical placement moves pass 1 / pass 2 by up to 15 %
                                         from one allocation to the next; worth its ~5 ms per candidate for contexts that sort many genomes */
-       KR_OPT_ISECT_KERNEL = 8,      /* 0 (default) the persistent, pipelined intersect kernel over items of whole buckets wherever a
-                                        (left,right) group lies inside one fine bucket; 1: one workgroup per chunk everywhere */
+       KR_OPT_ISECT_KERNEL = 8,      /* 0 (default) the persistent, pipelined intersect kernels over items of whole buckets wherever a
+                                        (left,right) group lies inside one fine bucket (with 32-bit heads where the geometry allows);
+                                        1: one workgroup per chunk everywhere; 2: pipelined with 64-bit heads only */
        KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
                                         of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
                                         ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */
@@ -312,9 +313,9 @@ double  kr_debug_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t*
 /* measured streaming-copy rate of this device (read + write GB/s): bench.py reports the roofline
  * fraction against it beside the 8 TB/s specification figure */
 double  kr_debug_copy_gbps(kr_ctx*, size_t bytes, int reps);
-/* the pipelined intersect kernel: items that went to the chunk kernel (oversized), slices redone by chunks,
- * threads per workgroup and log2(buckets per item) of the latest launch */
-int     kr_debug_isect(kr_ctx*, int64_t* out4);
+/* the pipelined intersect kernels: items that went to the chunk kernel (oversized), slices redone by chunks,
+ * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5..7] = 0 */
+int     kr_debug_isect(kr_ctx*, int64_t* out8);
 /* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
 int64_t kr_debug_budget_left(kr_ctx*);
 int     kr_debug_budget_set(kr_ctx*, int64_t left);

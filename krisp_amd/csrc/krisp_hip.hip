@@ -35,6 +35,7 @@
 #include "k_sort2.inc"       // pass 1 / pass 2 / LDS sort as persistent, software-pipelined kernels (buffer loads, counted waits)
 #include "k_intersect.inc"   // n-way intersection, candidate compaction, collection, list merge
 #include "k_intersect3.inc"  // the same intersection as a persistent, software-pipelined kernel (items of whole buckets)
+#include "k_intersect3t.inc" // ... with 32-bit heads where the geometry allows
 #include "k_text.inc"        // the reference reader on the device: file text -> upload buffer
 #include "k_wide.inc"        // wide path kernels, copy kernel
 

@@ -156,7 +156,7 @@ def test_sort_in_key_space_slices_vs_oracle(N, K, sb, n, L, D, R, omit):
 
 
 @pytest.mark.parametrize("sb,generic,fmt,kern", [(1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (2, 1, 1, 0),
-                                                 (0, 0, 0, 1), (1, 0, 1, 1)])
+                                                 (0, 0, 0, 1), (1, 0, 1, 1), (0, 0, 0, 2), (1, 0, 1, 2)])
 @pytest.mark.parametrize("L,D,R,length,n", [(25, 1, 2, 200_000, 4), (12, 4, 12, 100_000, 3), (8, 1, 4, 20_000, 5)])
 def test_intersect_and_collect_under_every_option(N, K, sb, generic, fmt, kern, L, D, R, length, n):
     """the result-neutral options of kr_set_option (key-space slices, generic intersect sub-tiles,
@@ -329,12 +329,13 @@ def test_intersect_and_collect(N, K, L, D, R, length, n):
             assert np.array_equal(got["out_mask"], want_f["out_mask"])
 
 
-def _check_intersect(N, K, texts, flags, L, D, R, env=None):
-    """n-way intersect + collect of `texts` against the packed oracle, unfiltered and filtered"""
+def _check_intersect(N, K, texts, flags, L, D, R, env=None, kern=0):
+    """n-way intersect + collect of `texts` against the packed oracle, unfiltered and filtered
+    (kern: KR_OPT_ISECT_KERNEL -- 0 the pipelined kernels, 32-bit heads where the geometry allows; 2 64-bit heads)"""
     n = len(texts)
     want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
     with N.Engine() as e:
-        e.set_option(N.OPT_ISECT_KERNEL, 0)            # (these tests are about the pipelined kernel, whatever the environment says)
+        e.set_option(N.OPT_ISECT_KERNEL, kern)         # (these tests are about the pipelined kernels, whatever the environment says)
         e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
         for i, t in enumerate(texts):
             assert e.add(i, t) == len(want_keys[i])
@@ -359,19 +360,29 @@ def test_pipelined_intersect_item_shapes(N, K, length, threads, mlog):
     fam = synth.family(length % 97, 2, 1, length, records=3, mu=0.01, snp_every=1500)
     texts = [t for _, _, t in fam]
     texts[1] = texts[1][: len(texts[1]) - 37]            # the anchor (fewest keys) is not genome 0
-    info, _ = _check_intersect(N, K, texts, [f for _, f, _ in fam], 20, 2, 5)
-    assert (threads is None or info["threads"] == threads) and info["slices_redone"] == 0
-    if mlog is not None:
-        assert info["buckets_per_item_log2"] == mlog
+    for kern in (0, 2):
+        info, _ = _check_intersect(N, K, texts, [f for _, f, _ in fam], 20, 2, 5, kern=kern)
+        assert (threads is None or info["threads"] == threads) and info["slices_redone"] == 0
+        assert threads is None or info["heads32"] == (1 if kern == 0 else 0)     # (the tiny case: many buckets per item, 64-bit heads)
+        if mlog is not None:
+            assert info["buckets_per_item_log2"] == mlog
 
 
-@pytest.mark.parametrize("L,D,R,n", [(20, 1, 6, 7), (11, 6, 10, 4), (9, 10, 9, 5), (12, 16, 4, 3), (16, 0, 16, 6), (10, 1, 3, 32)])
-def test_pipelined_intersect_formats_and_genome_counts(N, K, L, D, R, n):
-    """every per-prefix state format (D <= 4, <= 8, <= 16) and 3 .. 32 genomes per call"""
+@pytest.mark.parametrize("L,D,R,n,length,heads32", [(20, 1, 6, 7, 120_000, 1), (11, 6, 10, 4, 120_000, 1), (9, 10, 9, 5, 120_000, 1),
+                                                    (12, 16, 4, 3, 120_000, 0), (16, 0, 16, 6, 120_000, 0), (10, 1, 3, 32, 120_000, 0),
+                                                    (25, 1, 2, 3, 1_300_000, 1), (16, 0, 16, 3, 2_000_000, 0), (15, 2, 15, 3, 900_000, 0),
+                                                    (13, 2, 13, 3, 900_000, 1)])
+def test_pipelined_intersect_formats_and_genome_counts(N, K, L, D, R, n, length, heads32):
+    """every per-prefix state format (D <= 4, <= 8, <= 16), 3 .. 32 genomes per call, both pipelined kernels (32-bit
+    heads where the sub-bin field lies at most 32 bits above the prefix's lowest bit, else 64-bit heads; and 64-bit
+    heads on request)"""
     from krisp_amd import synth
-    fam = synth.family(L + n, (n + 1) // 2, n // 2, 120_000, records=2, mu=0.004, snp_every=700)
+    fam = synth.family(L + n, (n + 1) // 2, n // 2, length, records=2, mu=0.004, snp_every=700)
     info, _ = _check_intersect(N, K, [t for _, _, t in fam], [f for _, f, _ in fam], L, D, R)
-    assert info["threads"] >= 256
+    assert info["threads"] >= 256 and info["heads32"] == heads32
+    if heads32:
+        info, _ = _check_intersect(N, K, [t for _, _, t in fam], [f for _, f, _ in fam], L, D, R, kern=2)
+        assert info["heads32"] == 0
 
 
 def test_pipelined_intersect_runs_of_equal_prefixes(N, K):
@@ -391,6 +402,9 @@ def test_pipelined_intersect_runs_of_equal_prefixes(N, K):
         texts.append(np.concatenate([acgt[a], [10], acgt[b2], [10], acgt[a[:40_000]]]).astype(np.uint8))
     _check_intersect(N, K, texts, [1, 1, 0, 0], 8, 2, 3)
     _check_intersect(N, K, texts, [1, 0, 1, 0], 13, 1, 2)
+    info, _ = _check_intersect(N, K, texts, [1, 0, 1, 0], 20, 1, 4)
+    assert info["heads32"] == 1
+    _check_intersect(N, K, texts, [1, 0, 1, 0], 20, 1, 4, kern=2)
 
 
 def test_pipelined_intersect_oversized_items(N, K, monkeypatch):
