@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--place-tries", type=int, default=None,
                     help="KR_OPT_PLACE_TRIES: candidate allocations of the pass-1 output buffer, the fastest is kept "
                          "(default: the library's own default, 8 -- what the command line runs with, too)")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="sort lanes (KR_OPT_LANES; default: the library's, 3): consecutive genome sorts overlap on the device")
     ap.add_argument("--length", type=int, default=None, help="bases per genome (overrides the config's: a custom workload)")
     ap.add_argument("--per-gpu", type=int, default=None, help="genomes per GPU (overrides the config's)")
     ap.add_argument("--ldr", type=int, nargs=3, default=None, help="conserved-left diagnostic conserved-right")
@@ -291,6 +293,8 @@ def main():
     if args.place_tries is not None:
         eng.set_option(_native.OPT_PLACE_TRIES, args.place_tries)
     place_tries = args.place_tries if args.place_tries is not None else int(os.environ.get("KR_PLACE_TRIES", "8"))
+    lanes = args.lanes if args.lanes is not None else int(os.environ.get("KR_LANES", "3"))
+    eng.set_option(_native.OPT_LANES, lanes)
     max_bases = max(len(t) for _, _, t in genomes)
     if wide:
         eng.set_params_wide(L, Dg, R, omit_soft=False, max_bases=max_bases)
@@ -328,9 +332,14 @@ def main():
     # calibration (untimed, after the warm-up): every stage bracketed by HIP events -> the stage
     # table and the dominant kernel.  Event pairs around all ~60 launches of a step cost ~4 % of it,
     # so the timed region below brackets the launches of the dominant kernel only.
+    # The calibration runs with ONE sort lane, every kernel alone on the device: with the library's lanes the sorts
+    # of consecutive genomes overlap, a kernel's launch then lasts longer (it shares the device) while the step gets
+    # shorter.  The timed region runs as the library does; its bracket around the dominant kernel is the contract's
+    # `roofline` (live, overlapped), the calibration's the kernel by itself (`roofline.alone`).
     calib = {}
     dom_stage = None
     if not args.no_stage_timers:
+        eng.set_option(_native.OPT_LANES, 1)
         eng.stage_enable(True)
         eng.stage_reset()
         ncal = 3
@@ -340,6 +349,8 @@ def main():
         calib = {s: (v[0] / ncal, v[1] // ncal) for s, v in eng.stage_times().items() if v[1]}
         dom_stage = max((s for s in calib if s in stage_bytes_all), key=lambda s: calib[s][0])
         eng.stage_select([dom_stage])
+        eng.set_option(_native.OPT_LANES, lanes)
+        step()
         eng.stage_reset()
         barrier()
     t0 = time.perf_counter()
@@ -379,6 +390,8 @@ def main():
                 stage_bytes["hist8"] = 0.1875 + 8.0
             per_launch = kmers_local * args.steps / launches
             achieved = stage_bytes[dom] * kmers_local * args.steps / (ms * 1e-3) / 1e9
+            alone_ms = calib[dom][0] / max(calib[dom][1], 1)        # per launch, the kernel by itself (one lane)
+            alone = stage_bytes[dom] * per_launch / (alone_ms * 1e-3) / 1e9
             # HBM bytes per launch of the same kernel from the PMC counters (rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE passes of this command, profiles/make_traffic.py), valid for
             # the default workload only; expressed like `achieved`: bytes per launch / launch time
@@ -400,6 +413,10 @@ def main():
                     "copy_peak_guide": 6290.0,
                     "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                    "sort_lanes": lanes,
+                    "alone": {"what": "the same kernel with one sort lane (nothing else on the device), calibration steps",
+                              "avg_launch_ms": round(alone_ms, 4), "achieved": round(alone, 1),
+                              "frac": round(alone / HBM_PEAK_GBPS, 4), "frac_of_copy_peak": round(alone / copy_gbps, 4)},
                     "pipeline_model_bytes_per_kmer": model_b,
                     "pipeline_model_GBps": round(model_b * value / world / 1e9, 1),
                     "pipeline_model_frac": round(model_b * value / world / 1e9 / HBM_PEAK_GBPS, 4),
@@ -422,7 +439,7 @@ def main():
                                "sort every genome + n-way intersect + filter"
                                + ("" if args.no_collect else " + collect the candidate records (resident in HBM)"),
                        "kmers_per_step": kmers_total, "candidates": int(ncand), "records": int(records_total),
-                       "place_tries": place_tries,
+                       "place_tries": place_tries, "sort_lanes": lanes,
                        "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else
                                       f" + tree-reduce of candidates ({args.transport})")},
             "roofline": roof,

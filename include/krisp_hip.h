@@ -278,6 +278,10 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
        KR_OPT_ISECT_KERNEL = 8,      /* 0 (default) the persistent, pipelined intersect kernels over items of whole buckets wherever a
                                         (left,right) group lies inside one fine bucket (with 32-bit heads where the geometry allows);
                                         1: one workgroup per chunk everywhere; 2: pipelined with 64-bit heads only */
+       KR_OPT_LANES = 9,             /* 1 .. 8 (default 3): sort lanes.  Consecutive kr_genome_sort calls go to consecutive lanes (own
+                                        stream, own scratch: 16 bytes per base each) and overlap on the device; kr_intersect and
+                                        every call that reads a sorted genome join them.  Wide windows and key-space slices use one
+                                        lane whatever the setting.  May be set at any time */
        KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
                                         of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
                                         ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */

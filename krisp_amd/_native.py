@@ -25,6 +25,7 @@ COMM_ID_BYTES = 128
 SOFT_MAP, SOFT_OMIT = 0, 1
 OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE, OPT_WIDE_SLOTS, OPT_WIDE_ORDERED, OPT_PLACE_TRIES = 1, 2, 3, 4, 5, 6, 7
 OPT_ISECT_KERNEL = 8
+OPT_LANES = 9
 ERR_KEY, ERR_HOST = -5, -6
 STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
@@ -321,7 +322,7 @@ class Engine:
         return out[:m]
 
     def set_option(self, option, value):
-        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ISECT_KERNEL, OPT_WIDE_SLOTS); before set_params"""
+        """result-neutral options (OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ISECT_KERNEL, OPT_WIDE_SLOTS, OPT_LANES); before set_params (OPT_LANES: any time)"""
         self._check(self.lib.kr_set_option(self.ctx, option, int(value)), "kr_set_option")
 
     def set_params(self, L, D, R, omit_soft=False, max_bases=0):
