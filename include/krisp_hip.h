@@ -278,10 +278,12 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
        KR_OPT_ISECT_KERNEL = 8,      /* 0 (default) the persistent, pipelined intersect kernels over items of whole buckets wherever a
                                         (left,right) group lies inside one fine bucket (with 32-bit heads where the geometry allows);
                                         1: one workgroup per chunk everywhere; 2: pipelined with 64-bit heads only */
-       KR_OPT_LANES = 9,             /* 1 .. 8 (default 3): sort lanes.  Consecutive kr_genome_sort calls go to consecutive lanes (own
-                                        stream, own scratch: 16 bytes per base each) and overlap on the device; kr_intersect and
-                                        every call that reads a sorted genome join them.  Wide windows and key-space slices use one
-                                        lane whatever the setting.  May be set at any time */
+       KR_OPT_LANES = 9,             /* sort lanes, 1 .. 8: consecutive kr_genome_sort calls go to consecutive lanes (own stream, own
+                                        scratch: 16 bytes per base each) and overlap on the device (3 lanes: -7 % per step on 4 x 50
+                                        Mbp); kr_intersect and every call that reads a sorted genome join them.  0 (default):
+                                        automatic -- one lane until the context has sorted 16 genomes (a lane costs ~10 ms to set
+                                        up, more than a one-shot run gets back), 3 from then on.  Wide windows and key-space slices
+                                        use one lane whatever the setting.  May be set at any time */
        KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
                                         of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
                                         ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */
@@ -318,7 +320,8 @@ double  kr_debug_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t*
  * fraction against it beside the 8 TB/s specification figure */
 double  kr_debug_copy_gbps(kr_ctx*, size_t bytes, int reps);
 /* the pipelined intersect kernels: items that went to the chunk kernel (oversized), slices redone by chunks,
- * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5..7] = 0 */
+ * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
+ * now; out[6..7] = 0 */
 int     kr_debug_isect(kr_ctx*, int64_t* out8);
 /* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
 int64_t kr_debug_budget_left(kr_ctx*);

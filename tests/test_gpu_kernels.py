@@ -664,6 +664,40 @@ def test_device_reader_equals_the_host_parser(N, tmp_path):
         assert np.array_equal(e.keys(1), e.keys(2))
 
 
+def test_sort_lanes_automatic_and_fixed(N, K):
+    """KR_OPT_LANES: a context starts with one sort lane and takes three once it has sorted 16 genomes (consecutive
+    sorts then overlap on the device, each lane with its own scratch); a fixed number on request, changed at any
+    time.  The keys of 40 genomes sorted back to back -- nothing waits in between -- and the intersections over them
+    equal the oracle's whatever lane took which genome."""
+    from krisp_amd import synth
+    L, D, R = 20, 1, 5
+    fam = synth.family(77, 20, 20, 90_000, records=2, mu=0.004, snp_every=900)
+    texts = [t for _, _, t in fam]
+    flags = [f for _, f, _ in fam]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
+    with N.Engine() as e:
+        e.set_option(N.OPT_LANES, 0)
+        e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
+        for i, t in enumerate(texts):
+            e.upload(i, t)
+        for i in range(len(texts)):
+            e.sort(i)
+            assert e.debug_isect()["sort_lanes"] == (1 if i < 15 else 3), i
+        ids = list(range(8, 40))
+        want = K.intersect([want_keys[i] for i in ids], [flags[i] for i in ids], L, D, R, apply_filter=False)
+        assert e.intersect(ids, [flags[i] for i in ids], apply_filter=False) == len(want)
+        assert np.array_equal(e.cands()["prefix"], want["prefix"])
+        for i in range(len(texts)):
+            assert np.array_equal(e.keys(i), want_keys[i]), i
+        for lanes in (5, 2, 1, 8):
+            e.set_option(N.OPT_LANES, lanes)
+            for i in range(12):
+                e.sort(i)
+            assert e.debug_isect()["sort_lanes"] == lanes
+            for i in (0, 5, 11):
+                assert np.array_equal(e.keys(i), want_keys[i]), (lanes, i)
+
+
 def test_intersect_right_behind_sorts_that_need_the_merge_fallback(N, K):
     """kr_intersect does not wait for the sorts: it looks at what they left open after its own synchronisation.
     Genomes with satellites (buckets too large for the LDS sort) are sorted and intersected WITHOUT asking for their
