@@ -269,7 +269,8 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
                                         large-genome path, pass 0 + per-slice pass 1) */
        KR_OPT_GENERIC_INTERSECT = 2, /* 1: every intersect sub-tile takes the generic path (key-count
                                         splits, ranges from the prefixes) instead of whole-bucket sub-tiles */
-       KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4 */
+       KR_OPT_ISECT_FORMAT = 3,      /* 0 automatic; 1: the narrow per-prefix state also for D <= 4; 2: automatic, but never the
+                                        32-bit word per prefix that one diagnostic column and <= 24 genomes otherwise get */
        KR_OPT_ABLATE = 4,            /* timing aids of kr_debug_*; refused unless built with -DKR_ABLATE */
        KR_OPT_WIDE_SLOTS = 5,        /* wide path: 1 (default) dictionaries also as one-sector slot tables, 0 index + sorted keys only */
        KR_OPT_PLACE_TRIES = 7,       /* 1 .. 16 (default 8): candidate allocations of the pass-1 output buffer (>= 256 MB), each timed under

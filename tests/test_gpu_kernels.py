@@ -156,7 +156,7 @@ def test_sort_in_key_space_slices_vs_oracle(N, K, sb, n, L, D, R, omit):
 
 
 @pytest.mark.parametrize("sb,generic,fmt,kern", [(1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (2, 1, 1, 0),
-                                                 (0, 0, 0, 1), (1, 0, 1, 1), (0, 0, 0, 2), (1, 0, 1, 2)])
+                                                 (0, 0, 0, 1), (1, 0, 1, 1), (0, 0, 0, 2), (1, 0, 1, 2), (0, 0, 2, 0)])
 @pytest.mark.parametrize("L,D,R,length,n", [(25, 1, 2, 200_000, 4), (12, 4, 12, 100_000, 3), (8, 1, 4, 20_000, 5)])
 def test_intersect_and_collect_under_every_option(N, K, sb, generic, fmt, kern, L, D, R, length, n):
     """the result-neutral options of kr_set_option (key-space slices, generic intersect sub-tiles,
@@ -194,7 +194,9 @@ def test_options_are_checked(N, monkeypatch):
         with pytest.raises(N.KrispHipError):
             e.set_option(N.OPT_SLICE_BASES, 5)
         with pytest.raises(N.KrispHipError):
-            e.set_option(N.OPT_ISECT_FORMAT, 2)
+            e.set_option(N.OPT_ISECT_FORMAT, 3)
+        with pytest.raises(N.KrispHipError):
+            e.set_option(N.OPT_LANES, 9)
         with pytest.raises(N.KrispHipError):
             e.set_option(N.OPT_ABLATE, 64)
         with pytest.raises(N.KrispHipError):
@@ -329,13 +331,14 @@ def test_intersect_and_collect(N, K, L, D, R, length, n):
             assert np.array_equal(got["out_mask"], want_f["out_mask"])
 
 
-def _check_intersect(N, K, texts, flags, L, D, R, env=None, kern=0):
+def _check_intersect(N, K, texts, flags, L, D, R, env=None, kern=0, fmt=0):
     """n-way intersect + collect of `texts` against the packed oracle, unfiltered and filtered
     (kern: KR_OPT_ISECT_KERNEL -- 0 the pipelined kernels, 32-bit heads where the geometry allows; 2 64-bit heads)"""
     n = len(texts)
     want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
     with N.Engine() as e:
         e.set_option(N.OPT_ISECT_KERNEL, kern)         # (these tests are about the pipelined kernels, whatever the environment says)
+        e.set_option(N.OPT_ISECT_FORMAT, fmt)
         e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
         for i, t in enumerate(texts):
             assert e.add(i, t) == len(want_keys[i])
@@ -383,6 +386,9 @@ def test_pipelined_intersect_formats_and_genome_counts(N, K, L, D, R, n, length,
     if heads32:
         info, _ = _check_intersect(N, K, [t for _, _, t in fam], [f for _, f, _ in fam], L, D, R, kern=2)
         assert info["heads32"] == 0
+        if D == 1:      # (one column, <= 24 genomes: a 32-bit word per prefix; KR_OPT_ISECT_FORMAT = 2: the 64-bit state)
+            info, _ = _check_intersect(N, K, [t for _, _, t in fam], [f for _, f, _ in fam], L, D, R, fmt=2)
+            assert info["heads32"] == 1
 
 
 def test_pipelined_intersect_runs_of_equal_prefixes(N, K):
