@@ -11,7 +11,8 @@ import sys
 
 KERNEL_STAGE = {"k_pack": "pack", "k_hist8": "hist8", "k_reduce8": "reduce8", "k_scatter1p": "scatter1",
                 "k_hist2": "hist2", "k_hist16": "hist2", "k_scan2": "scan2", "k_scatter2": "scatter2", "k_localsort2": "localsort",
-                "k_intersect": "intersect", "k_intersect3": "intersect"}       # (k_intersect3 last: it is the one that moves the bytes)
+                "k_intersect": "intersect", "k_intersect3": "intersect", "k_intersect3t": "intersect"}
+# (the pipelined kernels last: whichever ran is the one that moves the bytes; k_intersect then only takes oversized items)
 
 
 def load(path, counter):

@@ -3,6 +3,7 @@
 # for SURVEY 8(d)'s secondary inputs, into gpurun_out/<round>/variants/ (copy to profiles/<round>/variants/ afterwards):
 #   bash tools/profile_variants.sh r03
 R=${1:-r03}
+PART=${2:-all}      # "a": configs[1] variants + configs[3]; "b": configs[4], configs[2], transports; "all"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R/variants
 mkdir -p "$OUT"
@@ -16,13 +17,20 @@ except Exception as e:
     print("   no line:", e)
 PY
 }
+if [ "$PART" != b ]; then
 run configs1_4x50Mbp --config 1 --steps 10 --warmup 2
 run configs1_independent --config 1 --steps 10 --warmup 2 --no-cpu-baseline --independent
 run configs1_masked --config 1 --steps 10 --warmup 2 --no-cpu-baseline --masked
+KR_LANES=1 run configs1_one_sort_lane --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 KR_LANES=2 run configs1_two_sort_lanes --config 1 --steps 10 --warmup 2 --no-cpu-baseline
+KR_LANES=4 run configs1_four_sort_lanes --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 KR_ISECT_KERNEL=1 run configs1_chunk_intersect_kernel --config 1 --steps 10 --warmup 2 --no-cpu-baseline
+KR_ISECT_KERNEL=2 run configs1_pipelined_64bit_heads --config 1 --steps 10 --warmup 2 --no-cpu-baseline
+KR_ISECT_FMT=2 run configs1_32bit_heads_64bit_state --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 run configs3_per_gpu_load_4x100Mbp --config 3 --steps 10 --warmup 2 --no-cpu-baseline
 run configs3_all_32x100Mbp_one_gpu --config 3 --per-gpu 32 --steps 3 --warmup 1 --no-cpu-baseline
+fi
+if [ "$PART" != a ]; then
 run configs4_2x3Gbp_28_1_2 --config 4 --no-cpu-baseline
 run configs2_8x500Mbp_32_60_32 --config 2
 run configs2_8x500Mbp_32_60_32_mu0.001 --config 2 --mu 0.001 --records 24 --snp-every 20000 --no-cpu-baseline
@@ -38,3 +46,4 @@ for N in 2 4; do
   for p in $pids; do wait $p || echo "rank failed"; done
   tail -c 600 "$OUT/rehearsal_n${N}_rank0.json" | head -c 600; echo
 done
+fi
