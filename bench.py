@@ -414,6 +414,9 @@ def main():
                     "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                     "sort_lanes": lanes,
+                    "note": (None if lanes <= 1 or wide else
+                             f"{lanes} sort lanes: the launches of this kernel run beside the kernels of other genomes' sorts, so a "
+                             "launch lasts longer while the step gets shorter; `alone` is the same kernel by itself"),
                     "alone": {"what": "the same kernel with one sort lane (nothing else on the device), calibration steps",
                               "avg_launch_ms": round(alone_ms, 4), "achieved": round(alone, 1),
                               "frac": round(alone / HBM_PEAK_GBPS, 4), "frac_of_copy_peak": round(alone / copy_gbps, 4)},
