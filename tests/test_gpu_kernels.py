@@ -374,7 +374,8 @@ def test_pipelined_intersect_item_shapes(N, K, length, threads, mlog):
 @pytest.mark.parametrize("L,D,R,n,length,heads32", [(20, 1, 6, 7, 120_000, 1), (11, 6, 10, 4, 120_000, 1), (9, 10, 9, 5, 120_000, 1),
                                                     (12, 16, 4, 3, 120_000, 0), (16, 0, 16, 6, 120_000, 0), (10, 1, 3, 32, 120_000, 0),
                                                     (25, 1, 2, 3, 1_300_000, 1), (16, 0, 16, 3, 2_000_000, 0), (15, 2, 15, 3, 900_000, 0),
-                                                    (13, 2, 13, 3, 900_000, 1)])
+                                                    (13, 2, 13, 3, 900_000, 1),
+                                                    (20, 1, 6, 24, 120_000, 1), (20, 1, 6, 25, 120_000, 1)])     # (24 genomes: the last that fit the 32-bit slot word)
 def test_pipelined_intersect_formats_and_genome_counts(N, K, L, D, R, n, length, heads32):
     """every per-prefix state format (D <= 4, <= 8, <= 16), 3 .. 32 genomes per call, both pipelined kernels (32-bit
     heads where the sub-bin field lies at most 32 bits above the prefix's lowest bit, else 64-bit heads; and 64-bit
