@@ -226,8 +226,8 @@ def cpu_baseline_wide(gen, L, D, R, per_gpu, mu, records, snp_every):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 2 for the multi-GB configs 2 and 4)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 2; 1 for configs 2 and 4)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 2 for the multi-GB configs 2 and 4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 for configs 2 and 4)")
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
                     help="BASELINE.json configs[N]: 1 = 4 x 50 Mbp 25/1/2 (default; at --gpus 8: 3 = 4 x 100 Mbp per GPU), "
                          "2 = 8 x 500 Mbp 32/60/32 (wide path), 4 = 2 x 3 Gbp 28/1/2")
@@ -278,8 +278,8 @@ def main():
         print("bench.py: the wide path (k > 32) is benchmarked on one GPU (DESIGN.md 7)", file=sys.stderr)
         sys.exit(2)
     big = length * per_gpu >= 2_000_000_000
-    steps = args.steps if args.steps is not None else (2 if big else 5)
-    warmup = args.warmup if args.warmup is not None else (1 if big else 2)
+    steps = args.steps if args.steps is not None else (2 if big else 20)
+    warmup = args.warmup if args.warmup is not None else (1 if big else 3)
     args.steps, args.warmup = steps, warmup
     config = C["gen"]
     genomes = make_genomes(config, rank, world, per_gpu, length, args.independent, args.masked,
