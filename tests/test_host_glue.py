@@ -376,6 +376,36 @@ def test_render_fast_path_equals_the_general_path():
         assert aln == "".join(amplicon.render_alignment(g, None, dot) + "\n" for g in groups)
 
 
+def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
+    """The library's kernels keep everything in registers and LDS: a private array indexed at run time or
+    spilled registers show as `ScratchSize` in hipcc's resource remarks -- and have crept in unnoticed through an
+    unrelated edit (spilled scalar registers in k_hist8w<2>, round 3).  Cross-compiles the translation unit (no GPU
+    needed) and reads the remarks."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "krisp_amd", "csrc", "krisp_hip.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-I" + os.path.join(root, "include"),
+                        "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, bad, seen = None, [], 0
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m:
+            seen += 1
+            if int(m.group(1)):
+                bad.append((name, int(m.group(1))))
+    assert seen > 50, "no resource remarks: has the flag changed?"
+    assert not bad, bad
+
+
 def test_scan_special_through_the_abi_equals_the_python_scan():
     """kr_scan_special (the C ABI's side channel for windows the 2-bit alphabet cannot carry) against
     the pure-Python scan on random texts: same IUPAC k-mers, same KeyError character"""
