@@ -705,6 +705,29 @@ def test_sort_lanes_automatic_and_fixed(N, K):
                 assert np.array_equal(e.keys(i), want_keys[i]), (lanes, i)
 
 
+def test_automatic_lanes_stay_at_one_when_their_scratch_does_not_fit(N, K):
+    """the 16th sort of a context would bring two more lanes; with no room left for their scratch (HBM budget) the
+    context keeps sorting on one lane instead of failing"""
+    from krisp_amd import synth
+    L, D, R = 20, 1, 5
+    fam = synth.family(78, 10, 10, 60_000, records=2, mu=0.004, snp_every=900)
+    texts = [t for _, _, t in fam]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
+    with N.Engine() as e:
+        e.set_option(N.OPT_LANES, 0)
+        e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
+        for i, t in enumerate(texts):
+            e.upload(i, t)
+        e.sort(0)
+        assert e.count(0) == len(want_keys[0])
+        assert e.lib.kr_debug_budget_set(e.ctx, 1 << 20) == 0          # (a lane's scratch is tens of megabytes)
+        for i in range(len(texts)):
+            e.sort(i)
+        assert e.debug_isect()["sort_lanes"] == 1
+        for i in range(len(texts)):
+            assert np.array_equal(e.keys(i), want_keys[i]), i
+
+
 def test_intersect_right_behind_sorts_that_need_the_merge_fallback(N, K):
     """kr_intersect does not wait for the sorts: it looks at what they left open after its own synchronisation.
     Genomes with satellites (buckets too large for the LDS sort) are sorted and intersected WITHOUT asking for their
