@@ -339,6 +339,7 @@ def _check_intersect(N, K, texts, flags, L, D, R, env=None, kern=0, fmt=0):
     with N.Engine() as e:
         e.set_option(N.OPT_ISECT_KERNEL, kern)         # (these tests are about the pipelined kernels, whatever the environment says)
         e.set_option(N.OPT_ISECT_FORMAT, fmt)
+        e.set_option(N.OPT_GENERIC_INTERSECT, 0)
         e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
         for i, t in enumerate(texts):
             assert e.add(i, t) == len(want_keys[i])
@@ -684,6 +685,7 @@ def test_sort_lanes_automatic_and_fixed(N, K):
     want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
     with N.Engine() as e:
         e.set_option(N.OPT_LANES, 0)
+        e.set_option(N.OPT_SLICE_BASES, 0)             # (key-space slices keep one lane)
         e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
         for i, t in enumerate(texts):
             e.upload(i, t)
@@ -715,6 +717,7 @@ def test_automatic_lanes_stay_at_one_when_their_scratch_does_not_fit(N, K):
     want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for t in texts]
     with N.Engine() as e:
         e.set_option(N.OPT_LANES, 0)
+        e.set_option(N.OPT_SLICE_BASES, 0)
         e.set_params(L, D, R, max_bases=max(len(t) for t in texts))
         for i, t in enumerate(texts):
             e.upload(i, t)
