@@ -507,6 +507,47 @@ def test_wide_right_flank_through_the_left_dictionary(N, geo, monkeypatch):
         assert np.array_equal(right1, right0)
 
 
+@pytest.mark.parametrize("geo", [(12, 30, 12), (32, 20, 32), (40, 12, 36), (20, 17, 9)])
+def test_wide_spectra_with_the_packed_kernels_change_nothing(N, geo, monkeypatch):
+    """With both strands in play kr_wide_run takes its flank spectra over every flank-long window with the packed
+    path's kernels -- a superset of the flanks of the valid amplicon-long windows.  Against the window-by-window
+    spectra (KR_WIDE_SPECTRUM=0): the same hits and groups, and the same k-mer record counts (amplicon-long windows,
+    counted by k_count_windows) on genomes with N runs, soft masks and many short records."""
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    L, D, R = geo
+    fam = _family(93, 4, 200_000)
+    rng = np.random.default_rng(7)
+    texts = []
+    for _, _, t in fam:
+        t = t.copy()
+        for p in rng.integers(0, len(t) - 50, size=40):          # N runs of 1 .. 40 bases, some next to record breaks
+            t[p:p + int(rng.integers(1, 41))] = ord("N")
+        for p in rng.integers(0, len(t), size=60):
+            t[p] = 10
+        texts.append(t)
+    names = [nm for nm, _, _ in fam]
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+
+    def run(packed):
+        monkeypatch.setenv("KR_WIDE_SPECTRUM", "1" if packed else "0")
+        with N.Engine() as e:
+            e.set_params_wide(L, D, R, max_bases=max(len(t) for t in texts))
+            for i, t in enumerate(texts):
+                e.upload(i, t)
+            n = e.wide_run(ids, flags, apply_filter=False)
+            counts = [int(x) for x in e.wide_fetch(N.WIDE_COUNTS)]
+            lines = amplicon.merged_lines(KF._groups_from_hits(e.wide_fetch(N.WIDE_HITS), texts, names, L, D, R))
+            return n, counts, lines, int(e.wide_fetch(N.WIDE_NGROUPS)[0]), e.wide_count(N.WIDE_DICT_LEFT)
+
+    n1, c1, l1, g1, d1 = run(True)
+    n0, c0, l0, g0, d0 = run(False)
+    assert n1 == n0 > 0 and l1 == l0 and g1 == g0
+    assert c1 == c0 and all(c > 0 for c in c0)
+    assert d1 >= d0
+
+
 def test_placement_tries_change_nothing_but_time(N, K):
     """KR_OPT_PLACE_TRIES: the pass-1 output buffer is chosen among several allocations (each timed under
     pass 1's write pattern); the result is the same as with a plain allocation"""
