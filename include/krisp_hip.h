@@ -283,8 +283,8 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
                                         scratch: 16 bytes per base each) and overlap on the device (3 lanes: -7 % per step on 4 x 50
                                         Mbp); kr_intersect and every call that reads a sorted genome join them.  0 (default):
                                         automatic -- one lane until the context has sorted 16 genomes (a lane costs ~10 ms to set
-                                        up, more than a one-shot run gets back), 3 from then on.  Wide windows and key-space slices
-                                        use one lane whatever the setting.  May be set at any time */
+                                        up, more than a one-shot run gets back), 3 from then on.  Key-space slices use one lane
+                                        whatever the setting, kr_wide_run two when more than one is asked for.  May be set at any time */
        KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
                                         of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
                                         ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */
