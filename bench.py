@@ -14,9 +14,12 @@ the library: csrc/h_comm.inc) -- the survivors broadcast and every rank collects
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N                   (no launcher: bench.py starts its own N ranks, self_launch below)
 
-The launcher only starts the processes (RANK / LOCAL_RANK / WORLD_SIZE): nothing here imports
-torch.  Barrier = stream sync + a reduction over all ranks (kr_comm_barrier); the step time is the
+A launcher only starts the processes (RANK / LOCAL_RANK / WORLD_SIZE): nothing here imports
+torch.  Every N runs the SAME per-GPU workload (configs[1]'s 4 x 50 Mbp per GPU, so the N = 1 line of
+a 1 / 2 / 4 / 8 sweep is the plain bench line and the sweep is one weak-scaling series); configs[3]'s
+4 x 100 Mbp per GPU is --config 3.  Barrier = stream sync + a reduction over all ranks (kr_comm_barrier); the step time is the
 MAX over ranks (kr_comm_allreduce).  Rank 0 prints ONE JSON line (DESIGN.md "Measurement").
 After the W warm-up steps come 3 untimed calibration steps with every kernel stage bracketed by
 HIP events (the stage table, the dominant kernel); the K timed steps bracket the dominant kernel's
@@ -223,14 +226,79 @@ def cpu_baseline_wide(gen, L, D, R, per_gpu, mu, records, snp_every):
             "reference_python": REFERENCE_PYTHON}
 
 
+def self_launch(n, timeout_s):
+    """`bench.py --gpus N` without a launcher: this process -- which has not touched the GPU and never will -- starts N
+    fresh copies of itself, one rank each (RANK / LOCAL_RANK / WORLD_SIZE as torch.distributed.run sets them, a private
+    rendezvous file), relays rank 0's JSON line, and ends every rank when one fails or the watchdog expires.  Returns
+    the exit code: 0, the first failing rank's code, or 124 for the watchdog."""
+    import shutil
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    td = tempfile.mkdtemp(prefix="krisp_bench_launch_")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, rc = [], 0
+    out0 = open(os.path.join(td, "rank0.out"), "w+")
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KRISP_LAUNCHER="torchrun",
+                       KRISP_COMM_FILE=os.path.join(td, "comm"))
+            # (own session = own process group: a rank and whatever it started can be ended by that group's id alone)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else sys.stderr, start_new_session=True))
+        t_end = time.time() + timeout_s
+        live = list(procs)
+        while live and not rc:
+            time.sleep(0.05)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f"bench.py: rank {procs.index(p)} exited with {code}: ending the other ranks", file=sys.stderr)
+                    break
+            if live and not rc and time.time() > t_end:
+                rc = 124
+                print(f"bench.py: no result within {timeout_s} s: ending all ranks", file=sys.stderr)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            pending = [p for p in procs if p.poll() is None]
+            if not pending:
+                break
+            for p in pending:
+                try:
+                    os.killpg(p.pid, sig)
+                except OSError:
+                    pass
+            t1 = time.time() + 5
+            while time.time() < t1 and any(p.poll() is None for p in pending):
+                time.sleep(0.05)
+        out0.seek(0)
+        text = out0.read()
+        if rc == 0:
+            sys.stdout.write(text)
+            sys.stdout.flush()
+        elif text:
+            sys.stderr.write(text)
+        return rc
+    finally:
+        out0.close()
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 2 for the multi-GB configs 2 and 4)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 for configs 2 and 4)")
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
-                    help="BASELINE.json configs[N]: 1 = 4 x 50 Mbp 25/1/2 (default; at --gpus 8: 3 = 4 x 100 Mbp per GPU), "
-                         "2 = 8 x 500 Mbp 32/60/32 (wide path), 4 = 2 x 3 Gbp 28/1/2")
+                    help="BASELINE.json configs[N]: 1 = 4 x 50 Mbp 25/1/2 per GPU (default at every --gpus), "
+                         "3 = 4 x 100 Mbp per GPU (quoted on 8 GPUs), 2 = 8 x 500 Mbp 32/60/32 (wide path), 4 = 2 x 3 Gbp 28/1/2")
     ap.add_argument("--place-tries", type=int, default=None,
                     help="KR_OPT_PLACE_TRIES: candidate allocations of the pass-1 output buffer, the fastest is kept "
                          "(default: the library's own default, 8 -- what the command line runs with, too)")
@@ -253,20 +321,23 @@ def main():
                     help="dir: rehearse the N > 1 flow with several ranks sharing the visible GPU (messages through files)")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the RCCL communicator even at world size 1 (plumbing self-test)")
+    ap.add_argument("--launch-timeout", type=int, default=1500,
+                    help="self-launched ranks (--gpus N without a launcher) are ended after this many seconds")
     args = ap.parse_args()
 
-    from krisp_amd import _native
     from krisp_amd import distributed as D
+    if args.gpus > 1 and not D.launched():
+        sys.exit(self_launch(args.gpus, args.launch_timeout))       # (before anything here touches the GPU)
+    from krisp_amd import _native
     rank, local_rank, world = D.env_rank_world()
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     if args.transport == "dir":
         local_rank = 0                          # rehearsal: the ranks share the GPU
 
-    cfg = args.config if args.config is not None else (3 if world == 8 else 1)
+    cfg = args.config if args.config is not None else 1     # (ONE per-GPU workload for every N: a weak-scaling series)
     C = CONFIGS[cfg]
     custom = args.length is not None or args.per_gpu is not None or args.ldr is not None
     length = args.length if args.length is not None else C["length"]
@@ -338,11 +409,12 @@ def main():
     # `roofline` (live, overlapped), the calibration's the kernel by itself (`roofline.alone`).
     calib = {}
     dom_stage = None
+    ncal = 3
+    gen_8d = (args.mu, args.records, args.snp_every) == (0.01, 16, 10000) and not (args.independent or args.masked)
     if not args.no_stage_timers:
         eng.set_option(_native.OPT_LANES, 1)
         eng.stage_enable(True)
         eng.stage_reset()
-        ncal = 3
         for _ in range(ncal):
             step()
         barrier()
@@ -392,34 +464,54 @@ def main():
             achieved = stage_bytes[dom] * kmers_local * args.steps / (ms * 1e-3) / 1e9
             alone_ms = calib[dom][0] / max(calib[dom][1], 1)        # per launch, the kernel by itself (one lane)
             alone = stage_bytes[dom] * per_launch / (alone_ms * 1e-3) / 1e9
-            # HBM bytes per launch of the same kernel from the PMC counters (rocprofv3 --pmc
-            # FETCH_SIZE / WRITE_SIZE passes of this command, profiles/make_traffic.py), valid for
-            # the default workload only; expressed like `achieved`: bytes per launch / launch time
-            traffic = None
+            # HBM bytes from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command,
+            # profiles/make_traffic.py): per launch of the dominant kernel and per step.  The file names the build it was
+            # measured with (hash of the HIP sources): with another build nothing is printed from it.
+            traffic, step_roof, traffic_meta = None, None, None
             tfile = os.path.join(ROOT, "profiles", "traffic_wide.json" if wide else "traffic.json")
-            if os.path.exists(tfile) and not custom and cfg in (1, 2) and world == 1:
+            if os.path.exists(tfile) and not custom and cfg in (1, 2) and world == 1 and gen_8d:
                 try:
-                    tb = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
-                    if wide:                # (launch sizes differ by phase and slice: bytes and time per STEP there)
-                        tb = json.load(open(tfile)).get(dom, {}).get("bytes_per_step")
-                        traffic = round(tb / (ms / args.steps * 1e-3) / 1e9, 1) if tb else None
+                    from krisp_amd import build as kb
+                    tj = json.load(open(tfile))
+                    meta = tj.get("_meta", {})
+                    if meta.get("source_sha16") != kb.source_sha16():
+                        traffic_meta = {"stale": f"{os.path.basename(tfile)} was measured with another build of the library "
+                                                 f"({meta.get('source_sha16')}, round {meta.get('round')}); this one is "
+                                                 f"{kb.source_sha16()}: no traffic figures"}
                     else:
-                        traffic = round(tb / (avg_ms * 1e-3) / 1e9, 1) if tb else None
-                except Exception:  # noqa: BLE001
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(achieved / copy_gbps, 4),
+                        traffic_meta = meta
+                        if wide:            # (launch sizes differ by phase and slice: bytes and time per STEP there)
+                            tb = tj.get(dom, {}).get("bytes_per_step")
+                            traffic = round(tb / (calib[dom][0] * 1e-3) / 1e9, 1) if tb else None
+                        else:
+                            tb = tj.get(dom, {}).get("bytes_per_launch")
+                            traffic = round(tb / (alone_ms * 1e-3) / 1e9, 1) if tb else None
+                        sb = tj.get("_step", {}).get("bytes_per_step")
+                        if sb:
+                            sg = sb / (ms_per_step * 1e-3) / 1e9
+                            step_roof = {"what": "HBM bytes of ALL kernels of one step (PMC: FETCH_SIZE x 2 + WRITE_SIZE, "
+                                                 "profiles/make_traffic.py) / ms_per_step of this run",
+                                         "bytes_per_step": sb, "ms_per_step": round(ms_per_step, 4), "achieved": round(sg, 1),
+                                         "frac": round(sg / HBM_PEAK_GBPS, 4), "frac_of_copy_peak": round(sg / copy_gbps, 4)}
+                except Exception as e:  # noqa: BLE001
+                    traffic_meta = {"error": str(e)}
+            # top level = the dominant kernel BY ITSELF (one sort lane, calibration steps of this run; the figure the
+            # rocprofv3 summary of `bench.py --lanes 1` shows); `live` = the same kernel inside the timed region, where
+            # its launches share the device with other genomes' kernels; `step` = the whole step on measured bytes
+            roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(alone, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(alone / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(alone_ms, 4), "launches": calib[dom][1] * ncal,
+                    "how": "algorithmic bytes per launch / average launch time (HIP events on the library's stream around each "
+                           "launch) of the dominant kernel by itself: calibration steps of this run with one sort lane",
+                    "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(alone / copy_gbps, 4),
                     "copy_peak_guide": 6290.0,
                     "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                    "sort_lanes": lanes,
-                    "note": (None if lanes <= 1 or wide else
-                             f"{lanes} sort lanes: the launches of this kernel run beside the kernels of other genomes' sorts, so a "
-                             "launch lasts longer while the step gets shorter; `alone` is the same kernel by itself"),
-                    "alone": {"what": "the same kernel with one sort lane (nothing else on the device), calibration steps",
-                              "avg_launch_ms": round(alone_ms, 4), "achieved": round(alone, 1),
-                              "frac": round(alone / HBM_PEAK_GBPS, 4), "frac_of_copy_peak": round(alone / copy_gbps, 4)},
+                    "live": {"what": f"the same kernel inside the timed region ({lanes} sort lane(s)"
+                                     + ("" if lanes <= 1 or wide else ": its launches run beside the kernels of other genomes' "
+                                        "sorts, so a launch lasts longer while the step gets shorter") + ")",
+                             "avg_launch_ms": round(avg_ms, 4), "launches": launches, "achieved": round(achieved, 1),
+                             "frac": round(achieved / HBM_PEAK_GBPS, 4), "sort_lanes": lanes},
+                    "step": step_roof, "traffic_source": traffic_meta,
                     "pipeline_model_bytes_per_kmer": model_b,
                     "pipeline_model_GBps": round(model_b * value / world / 1e9, 1),
                     "pipeline_model_frac": round(model_b * value / world / 1e9 / HBM_PEAK_GBPS, 4),
@@ -430,6 +522,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
+            "rccl_ranks": eng.comm_rccl_ranks(),     # (ncclCommCount: 0 = no RCCL communicator in this run)
             "config": {"workload": f"{name}: {per_gpu} synthetic {length / 1e6:g} Mbp random "
                                    f"genomes per GPU (half in / half out over the {per_gpu * world}-genome "
                                    f"family, mu={args.mu:g}, {args.records} records, planted SNP / {args.snp_every}"

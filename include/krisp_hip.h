@@ -150,6 +150,9 @@ int     kr_comm_init_dir(kr_ctx*, int rank, int world, const char* dir);
 int     kr_comm_destroy(kr_ctx*);
 int     kr_comm_rank(kr_ctx*);
 int     kr_comm_world(kr_ctx*);
+/* ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount); 0 without one (no communicator, or
+ * the file transport): bench.py prints it, so a line says whether xGMI carried the exchange */
+int     kr_comm_rccl_ranks(kr_ctx*);
 int     kr_comm_barrier(kr_ctx*);                               /* syncs the stream, then all ranks meet */
 /* vals[0..n) reduced over all ranks, n <= 8: op 0 = sum, 1 = max; the result on every rank */
 int     kr_comm_allreduce(kr_ctx*, double* vals, int n, int op);

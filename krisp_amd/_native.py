@@ -69,6 +69,7 @@ SYMBOLS = [
     ("kr_comm_destroy", _c.c_int, [_P]),
     ("kr_comm_rank", _c.c_int, [_P]),
     ("kr_comm_world", _c.c_int, [_P]),
+    ("kr_comm_rccl_ranks", _c.c_int, [_P]),
     ("kr_comm_barrier", _c.c_int, [_P]),
     ("kr_comm_allreduce", _c.c_int, [_P, _P, _c.c_int, _c.c_int]),
     ("kr_comm_allgather", _c.c_int, [_P, _P, _c.c_size_t, _P]),
@@ -224,7 +225,7 @@ def render_records(records, label_of, label_text, label_in, L, D, R, dot=False):
     lib = load()
     recs = np.ascontiguousarray(records, dtype=RECORD)
     lof = np.ascontiguousarray(label_of, dtype=np.uint32)
-    texts = [t.encode() for t in label_text]
+    texts = [t.encode("utf-8", "surrogateescape") for t in label_text]     # (labels come from file names)
     arr = (_c.c_char_p * max(len(texts), 1))(*texts)
     lin = None if label_in is None else np.ascontiguousarray(label_in, dtype=np.uint8)
     csv, align = _c.c_void_p(), _c.c_void_p()
@@ -237,7 +238,8 @@ def render_records(records, label_of, label_text, label_in, L, D, R, dot=False):
     if rc < 0:
         raise KrispHipError(f"kr_render_records: [{rc}]")
     try:
-        return (_c.string_at(csv, ncsv.value).decode("ascii"), _c.string_at(align, nalign.value).decode("ascii"), int(rc))
+        return (_c.string_at(csv, ncsv.value).decode("utf-8", "surrogateescape"),
+                _c.string_at(align, nalign.value).decode("utf-8", "surrogateescape"), int(rc))
     finally:
         lib.kr_text_free(csv)
         lib.kr_text_free(align)
@@ -426,6 +428,10 @@ class Engine:
     def comm_init_dir(self, rank, world, directory):
         """rehearsal transport: the same messages through files (ranks may share a GPU)"""
         self._check(self.lib.kr_comm_init_dir(self.ctx, rank, world, os.fsencode(directory)), "kr_comm_init_dir")
+
+    def comm_rccl_ranks(self):
+        """ranks of the RCCL communicator as ncclCommCount reports them; 0 without one (file transport, no communicator)"""
+        return int(self.lib.kr_comm_rccl_ranks(self.ctx))
 
     def comm_barrier(self):
         self._check(self.lib.kr_comm_barrier(self.ctx), "kr_comm_barrier")

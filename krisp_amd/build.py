@@ -17,6 +17,18 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def source_sha16():
+    """names the build: sha256 over the HIP sources and the header (what profiles/traffic.json says it was measured with)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.dirname(SRC)
+    for f in sorted(os.listdir(csrc)) + [os.path.join(INC, "krisp_hip.h")]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     csrc = os.path.dirname(SRC)          # krisp_hip.hip #includes its parts (k_*.inc kernels, h_*.inc host)
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INC, "krisp_hip.h")]

@@ -48,6 +48,17 @@ def env_rank_world():
     return 0, 0, 1
 
 
+def launched():
+    """True when a launcher's variable set (env_rank_world) is present: this process is one rank of a launch"""
+    e = os.environ
+    want = e.get("KRISP_LAUNCHER", "").strip().lower()
+    if want == "none":
+        return False
+    sets = {"torchrun": ("RANK", "WORLD_SIZE"), "mpi": ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE"),
+            "slurm": ("SLURM_PROCID", "SLURM_NTASKS")}
+    return any(r in e and w in e for nm, (r, w) in sets.items() if not want or nm == want)
+
+
 def rendezvous_path(world):
     """Where rank 0 leaves the RCCL unique id.  KRISP_COMM_FILE names it explicitly; else a name
     every rank of ONE launch derives alike and no other launch shares: the launcher's pid (the
@@ -76,6 +87,24 @@ def _write_atomic(path, data):
     os.replace(tmp, path)
 
 
+def private_dir(d):
+    """`d` as a directory of ours alone: created 0700, or -- when it exists -- owned by this user with no access for
+    anybody else; refused otherwise (a directory somebody else made under a guessable name in /tmp could feed a run
+    forged rendezvous answers or messages)."""
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"{d}: not a private directory of this user (owner {st.st_uid}, mode {st.st_mode & 0o777:o})")
+    return d
+
+
+def _rmdir_quiet(d):
+    try:
+        os.rmdir(d)
+    except OSError:
+        pass
+
+
 def rendezvous(base, rank, world, payload=b"", timeout_s=600):
     """Rank 0's `payload` and a per-run nonce for every rank, through files under `base`.rv --
     proof against what an earlier, crashed run left there.  Rank r > 0 announces itself with a
@@ -84,8 +113,7 @@ def rendezvous(base, rank, world, payload=b"", timeout_s=600):
     one); rank r accepts only an answer that starts with ITS token and acknowledges the nonce
     (ack_r); rank 0 returns once every rank has acknowledged THIS nonce, then removes the files.
     Returns (nonce, payload)."""
-    d = base + ".rv"
-    os.makedirs(d, mode=0o700, exist_ok=True)
+    d = private_dir(base + ".rv")
     t0 = time.time()
 
     def late(what):
@@ -113,6 +141,7 @@ def rendezvous(base, rank, world, payload=b"", timeout_s=600):
                     os.unlink(os.path.join(d, nm))
                 except OSError:
                     pass
+        _rmdir_quiet(d)                     # (stays when another run under the same name has files in it)
         return nonce.decode(), payload
     tok = secrets.token_hex(8).encode()
     _write_atomic(os.path.join(d, f"join_{rank}"), tok)
@@ -141,8 +170,8 @@ def connect(engine, rank, world, transport="rccl", path=None, timeout_s=600):
     cid = _native.comm_unique_id() if (transport == "rccl" and rank == 0) else b""
     nonce, cid = rendezvous(path, rank, world, bytes(cid), timeout_s)
     if transport == "dir":
-        os.makedirs(path + ".d", mode=0o700, exist_ok=True)
-        engine.comm_init_dir(rank, world, os.path.join(path + ".d", nonce))
+        # (the library removes the run's message directory, and this parent once it is empty, with the communicator)
+        engine.comm_init_dir(rank, world, os.path.join(private_dir(path + ".d"), nonce))
         return
     engine.comm_init(rank, world, cid)             # (collective: returns once every rank has joined)
 

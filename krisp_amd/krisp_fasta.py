@@ -516,12 +516,12 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         # ranks' device look-ups of the ACGT members (below), as find_regions does on one GPU
         specials_all = None
         if kinds[0]:
-            import pickle
+            import json         # (plain data: genome number -> [left, diag, right] strings; nothing executable crosses ranks)
             mine_sp = {g: [codec.split_window(w, Le, De, Re) for w in sp] for g, (_, _, sp) in zip(mine, loaded)}
             specials_all = [[] for _ in order]
-            for blob in eng.comm_allgather(pickle.dumps(mine_sp)):
-                for g, sp in pickle.loads(blob).items():
-                    specials_all[g] = sp
+            for blob in eng.comm_allgather(json.dumps(mine_sp).encode()):
+                for g, sp in json.loads(blob.decode()).items():
+                    specials_all[int(g)] = [tuple(w) for w in sp]
         stats = {"read_s": time.time() - t0}
         t1 = time.time()
         quirk_all_fail = do_filter and De == 0

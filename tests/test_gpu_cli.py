@@ -727,3 +727,31 @@ def test_krisp_fasta_command_line_over_several_ranks(world, name, tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert open(csvp).read() == case["csv"]
     assert open(aln).read() == case["align"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_starts_its_own_ranks_without_a_launcher(world, tmp_path):
+    """`python bench.py --gpus N` with no launcher variables: the parent starts N fresh ranks of itself before it touches
+    the GPU, relays rank 0's ONE JSON line and exits 0; the per-GPU workload is the same at every N
+    (configs[1] geometry; shortened here), so N = 1, 2, 4 are one weak-scaling series.  The ranks share the test GPU over
+    the file transport; rccl_ranks says so (0 = no RCCL communicator)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID", "KRISP_LAUNCHER", "KRISP_COMM_FILE")}
+    env["TMPDIR"] = str(tmp_path)
+    lines = {}
+    for n in (1, world):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--transport", "dir", "--steps", "2", "--warmup", "1",
+               "--length", "2000000", "--no-cpu-baseline", "--lanes", "1", "--launch-timeout", "600"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(out) == 1, r.stdout[-2000:]
+        lines[n] = json.loads(out[0])
+    one, many = lines[1], lines[world]
+    assert many["n_gpus"] == world and many["rccl_ranks"] == 0 and one["rccl_ranks"] == 0
+    assert many["scaling"] == "weak" and many["config"]["kmers_per_step"] > 0.95 * world * one["config"]["kmers_per_step"]
+    assert "custom" in many["config"]["baseline_config"]
+    # nothing of the launch is left behind (rendezvous files, message directories, the launcher's scratch)
+    assert [p for p in os.listdir(tmp_path) if p.startswith(("krisp_comm", "krisp_bench_launch"))] == []

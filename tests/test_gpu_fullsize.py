@@ -122,16 +122,22 @@ def test_c5_three_gbp_genomes():
 
 
 @BIG
-def test_c3_eight_half_gbp_genomes_long_amplicons():
+@pytest.mark.parametrize("mu,records,snp_every,min_groups", [
+    pytest.param(0.01, 16, 10000, 1000, id="survey_8d_generator_mu0.01_16records_snp10kb"),
+    pytest.param(0.001, 24, 20000, 100_000, id="close_relatives_mu0.001_24records_snp20kb")])
+def test_c3_eight_half_gbp_genomes_long_amplicons(mu, records, snp_every, min_groups):
     """BASELINE configs[2]: 8 x 500 Mbp (4 in / 4 out), 32/60/32 amplicon search -- the wide path with
     key-space slices; checked through properties (every group holds every genome, groups ascend,
-    one flank pair per group, a diagnostic column separates the groups)"""
+    one flank pair per group, a diagnostic column separates the groups).  Two inputs, named by their ids: SURVEY
+    8(d)'s own generator (mu = 0.01, 16 records, a planted SNP per 10 kb: what `bench.py --config 2` times) and
+    round 2's family of close relatives (mu = 0.001: ten times as many flanks survive the spectrum phase, > 10^5
+    groups to cut and render)"""
     import time
     from krisp_amd import _native, amplicon, synth
     from krisp_amd import krisp_fasta as KF
     L, D, R = 32, 60, 32
     t0 = time.time()
-    fam = synth.family(3, 4, 4, 500_000_000, records=24, mu=0.001, snp_every=20000)
+    fam = synth.family(3, 4, 4, 500_000_000, records=records, mu=mu, snp_every=snp_every)
     t1 = time.time()
     ids = list(range(len(fam)))
     flags = [f for _, f, _ in fam]
@@ -156,8 +162,8 @@ def test_c3_eight_half_gbp_genomes_long_amplicons():
         assert len({(a.left, a.right) for a in g}) == 1 and all(len(a.diag) == D for a in g)
         assert amplicon.ingroup_unique_columns(g, ingroup)
         pairs.append((g[0].left, g[0].right))
-    assert pairs == sorted(pairs) and len(set(pairs)) == len(pairs) and len(groups) > 100_000
-    print(f"\nC3: {len(groups)} groups, dictL {sizes[0]} dictR {sizes[1]} groups before the filter {sizes[2]}; "
+    assert pairs == sorted(pairs) and len(set(pairs)) == len(pairs) and len(groups) > min_groups
+    print(f"\nC3 (mu={mu:g}, {records} records, SNP per {snp_every}): {len(groups)} groups, dictL {sizes[0]} dictR {sizes[1]} groups before the filter {sizes[2]}; "
           f"generation {t1 - t0:.0f} s, upload {t2 - t1:.0f} s, first wide run (with allocations) {t3 - t2:.1f} s")
 
 

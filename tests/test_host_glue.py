@@ -569,3 +569,63 @@ def test_library_renderer_at_scale():
     dt = time.time() - t0
     assert fast == amplicon.render(amplicon.groups_from_records(recs, labels, L, D, R), ingroup)
     assert dt < 1.0, dt
+
+
+def test_bench_self_launch_ends_every_rank_when_one_fails(tmp_path):
+    """bench.py --gpus 3 without a launcher on a box without a GPU: every rank fails at kr_create, the parent -- which
+    never loads the library -- reports the first failure, ends the others and exits non-zero within seconds; with a
+    launcher's variables present it does not launch again"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KRISP_LAUNCHER")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # (also on a GPU box: no device for the ranks)
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    env["TMPDIR"] = str(tmp_path)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--length", "100000", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "ending the other ranks" in r.stderr and "no HIP device" in r.stderr, r.stderr[-1500:]
+    assert time.time() - t0 < 120
+    assert [p for p in os.listdir(tmp_path) if p.startswith("krisp_bench_launch")] == []
+    # a rank of somebody's launch (variables present) with the wrong --gpus: refused, not re-launched
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "the launcher started 2 rank(s)" in r.stderr
+
+
+def test_library_renderer_keeps_labels_that_are_not_ascii():
+    """labels come from file names (shared.py:34-73): a name outside ASCII goes through kr_render_records as UTF-8 and
+    comes back as the general path renders it (the library's text was decoded as ASCII)"""
+    from krisp_amd import _native, amplicon
+    L, D, R = 5, 1, 3
+    labels = ["Phytophthora_ramorum_é", "outgroup_日本", "plain"]
+    recs = []
+    for i, pre in enumerate((3, 77, 1000)):
+        key = pre << (64 - 2 * (L + R))
+        for g, d in ((0, 1), (1, 2), (2, 2 if i else 3)):
+            recs.append((key | (d << (64 - 2 * (L + D + R))), g, 1 + (g == 1)))
+    recs = np.array(recs, dtype=_native.RECORD)
+    for ingroup in (None, frozenset(labels[:1])):
+        for dot in (False, True):
+            rg = amplicon.RecordGroups(recs, labels, L, D, R)
+            want = amplicon.render(amplicon.groups_from_records(recs, labels, L, D, R), ingroup, dot)
+            assert rg.render_text(ingroup, dot) is not None
+            assert amplicon.render(rg, ingroup, dot) == want
+            assert "outgroup_日本(2)" in want[1]
+
+
+def test_rendezvous_refuses_a_directory_that_is_not_private(tmp_path):
+    """the .rv / .d directories hold the answers and messages a rank will trust: one that others can write to (made by
+    somebody else under the guessable name, or with a lax mode) is refused"""
+    from krisp_amd import distributed as D
+    base = str(tmp_path / "comm")
+    os.makedirs(base + ".rv", mode=0o777)
+    os.chmod(base + ".rv", 0o777)
+    with pytest.raises(PermissionError):
+        D.rendezvous(base, 1, 2, timeout_s=1)
+    os.chmod(base + ".rv", 0o700)
+    assert D.private_dir(base + ".rv") == base + ".rv"
+    assert D.rendezvous(base, 0, 1, b"x")[1] == b"x"

@@ -30,7 +30,7 @@ find "$OUT/stats1" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/
 find "$OUT/stats1" -type f ! -name "*kernel_stats.csv" -delete
 F=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
-python3 profiles/make_traffic.py "$F" "$W" "$OUT/traffic.json"
+python3 profiles/make_traffic.py "$F" "$W" "$OUT/traffic.json" "$R"
 # the raw per-dispatch csv files are large: keep the summaries only
 rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
 find "$OUT/stats" -type f ! -name "*kernel_stats.csv" -delete
