@@ -15,7 +15,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-XX
+# not part of a step: bench.py's copy-rate probe (k_copy16 and its two 1 GB fills), placement probes, the text reader
+NOT_A_STEP = ("k_copy16", "__amd_rocclr_", "k_probe_scatter", "k_tx_")
 
 KERNEL_STAGE = {"k_pack": "pack", "k_hist8": "hist8", "k_reduce8": "reduce8", "k_scatter1p": "scatter1",
                 "k_hist2": "hist2", "k_hist16": "hist2", "k_scan2": "scan2", "k_scatter2": "scatter2", "k_localsort2": "localsort",
