@@ -101,6 +101,17 @@ int kr_set_strands(kr_ctx*, int mode);
  * closed under complement.  After kr_set_params, before the first upload. */
 int kr_set_allow(kr_ctx*, unsigned base_mask);
 
+/* kstream's --sort-cols (kstream.py:83-119: `sort -t, -kN,N ...`, then GNU sort's whole-line compare) as a key layout:
+ * the window is cut into fields of widths[0..2] bases in line order (kstream.py:805-832; an empty field has width 0)
+ * and the key holds them in the order order[0], order[1], order[2] (a permutation of 0 1 2), so that the unsigned
+ * order of the keys is the order of that column list.  After kr_set_params(k, 0, 0, ...) with k = the sum of the
+ * widths (the window as ONE field), before the first upload.  A layout moves every field by one shift; it takes
+ * the orders whose fields need at most one distinct left and one distinct right shift (all but 2 1 0 with
+ * widths[0] != widths[2] and three non-empty fields: KR_ERR_PARAM, the caller sorts those on the host).  Such a
+ * context sorts and returns keys (kr_genome_sort, kr_genome_fetch_keys); kr_intersect and kr_collect -- whose
+ * prefix is the krisp_fasta layout's -- refuse it. */
+int kr_set_field_order(kr_ctx*, const int widths[3], const int order[3]);
+
 /* H2D copy of one genome's text + all device allocations it needs. */
 int kr_genome_upload(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
 /* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous. */

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("kr_genome_fetch_keys", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_genome_keys_in_order", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_set_allow", _c.c_int, [_P, _c.c_uint]),
+    ("kr_set_field_order", _c.c_int, [_P, _P, _P]),
     ("kr_genome_free", _c.c_int, [_P, _c.c_int]),
     ("kr_intersect", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_cands_count", _c.c_int64, [_P]),
@@ -368,6 +369,13 @@ class Engine:
         """kstream --allow on the device alphabet: an iterable of the bases (of ACGT) a k-mer may hold"""
         mask = sum(1 << "ACGT".index(b) for b in set(bases))
         self._check(self.lib.kr_set_allow(self.ctx, mask), "kr_set_allow")
+
+    def set_field_order(self, widths, order):
+        """kstream --sort-cols as a key layout: the window's fields (widths in line order) held in `order`; after
+        set_params(k, 0, 0).  Raises for the one order a layout cannot express (see include/krisp_hip.h)."""
+        w = np.asarray(list(widths) + [0] * (3 - len(widths)), dtype=np.int32)
+        o = np.asarray(order, dtype=np.int32)
+        self._check(self.lib.kr_set_field_order(self.ctx, _ptr(w), _ptr(o)), "kr_set_field_order")
 
     def keys_in_order(self, gid, n_bases):
         """keys of an uploaded genome in stream order (no sort)"""

@@ -65,6 +65,103 @@ def keys_to_fields_bytes(keys, fields, rna=False):
     return out.tobytes()
 
 
+def field_layout_ok(widths, order):
+    """can a key hold the window's fields (widths, line order) in `order` by moving each field with ONE shift --
+    at most one distinct left and one distinct right shift (kr_set_field_order, include/krisp_hip.h)?"""
+    src, at = [], 0
+    for w in widths:
+        src.append(at)
+        at += w
+    dst, at = {}, 0
+    for f in order:
+        dst[f] = at
+        at += widths[f]
+    left = {src[f] - dst[f] for f in range(len(widths)) if widths[f] and dst[f] < src[f]}
+    right = {dst[f] - src[f] for f in range(len(widths)) if widths[f] and dst[f] > src[f]}
+    return len(left) <= 1 and len(right) <= 1
+
+
+def keys_to_ordered_fields_bytes(keys, fields, order, rna=False):
+    """keys that hold the window's fields in `order` (kr_set_field_order; the krisp_fasta layout is order 0 2 1) -> bytes
+    of the sorted output: the fields in LINE order (widths `fields`, empty ones included) joined by ','."""
+    k = sum(fields)
+    m = keys_to_matrix(keys, k, 0, 0, rna)
+    koff, at = {}, 0
+    for f in order:
+        koff[f] = at
+        at += fields[f]
+    out = np.empty((len(m), k + len(fields)), dtype=np.uint8)
+    dst = 0
+    for f, w in enumerate(fields):
+        out[:, dst:dst + w] = m[:, koff[f]:koff[f] + w]
+        out[:, dst + w] = ord(",")
+        dst += w + 1
+    out[:, k + len(fields) - 1] = ord("\n")
+    return out.tobytes()
+
+
+def order_string(s, fields, order):
+    """the window string s with its fields (widths `fields`, line order) rearranged into `order`: what the sort compares"""
+    cuts, at = [], 0
+    for w in fields:
+        cuts.append(s[at:at + w])
+        at += w
+    return "".join(cuts[f] for f in order)
+
+
+def pack_plain(strings):
+    """ACGT strings (all of one length <= 32) -> uint64 keys, MSB aligned"""
+    if not strings:
+        return np.empty(0, dtype=np.uint64)
+    k = len(strings[0])
+    m = _CODE[np.frombuffer("".join(strings).encode(), dtype=np.uint8).reshape(len(strings), k)]
+    keys = np.zeros(len(strings), dtype=np.uint64)
+    for j in range(k):
+        keys |= m[:, j].astype(np.uint64) << np.uint64(62 - 2 * j)
+    return keys
+
+
+def insertion_index_ordered(keys, t):
+    """number of packed keys (pure ACGT strings in the key's field order) that sort before the string t, which holds at
+    least one character outside ACGT, in C-locale byte order (upper case before lower case, IUPAC letters among ACGT)"""
+    j = next(i for i, ch in enumerate(t) if ch not in "ACGT")
+    prefix = 0
+    for i in range(j):
+        prefix |= "ACGT".index(t[i]) << (62 - 2 * i)
+    c = sum(1 for b in "ACGT" if b < t[j])
+    bound = prefix + (c << (62 - 2 * j))    # c == 4 carries into the prefix: everything under it is smaller
+    if bound >= 1 << 64:
+        return len(keys)
+    return int(np.searchsorted(keys, np.uint64(bound), side="left"))
+
+
+def merged_ordered_blocks(keys, specials, fields, order, rna=False, chunk=1 << 22):
+    """Yield the sorted output as byte blocks: the packed keys decoded to lines with the k-mers the device alphabet cannot
+    carry (`specials`: window strings, pre-split) spliced in where the sort puts them"""
+    sp = sorted((order_string(s, fields, order), s) for s in specials)
+    cuts = [(insertion_index_ordered(keys, t), s) for t, s in sp]
+    pos = ci = 0
+    n = len(keys)
+    while pos < n or ci < len(cuts):
+        end = min(n, pos + chunk)
+        if ci < len(cuts):
+            end = min(end, cuts[ci][0])
+        if end > pos:
+            yield keys_to_ordered_fields_bytes(keys[pos:end], fields, order, rna)
+            pos = end
+        while ci < len(cuts) and cuts[ci][0] <= pos:
+            s = cuts[ci][1]
+            parts, at = [], 0
+            for w in fields:
+                parts.append(s[at:at + w])
+                at += w
+            line = ",".join(parts) + "\n"
+            if rna:
+                line = line.replace("T", "U").replace("t", "u")
+            yield line.encode("latin-1")
+            ci += 1
+
+
 def key_columns(key, L, D, R, rna=False):
     """one key -> (left, diag, right) str."""
     lut = "ACGU" if rna else "ACGT"

@@ -9,12 +9,14 @@ split=[L,-R], sort with sortcols=[0,2]) and its neighbours -- forward strand onl
 canonicals instead of complements, no split or a one-sided split, sort columns that
 leave the fields in line order, several k (one device sort per k, the sorted streams
 merged), --allow of plain bases (a base mask in the pack kernel), and no sort at all
-(keys in stream order, kr_genome_keys_in_order).  No CPU sort or k-mer generation stands
-in for that route when the library is missing: it raises.  Option sets outside it
-(expand-iupac, kept lower case, other column orders, --allow of ambiguity letters, k > 32)
-are outside the accelerated hot path and are served by the plain host
-generator chain below, as are inputs holding characters the 2-bit alphabet cannot carry
-under the forward / canonical modes.
+(keys in stream order, kr_genome_keys_in_order).  Round 4 adds: every sort-column order of the
+fields a key layout can hold (kr_set_field_order), --expand-iupac and streams that keep their lower
+case (the device sorts the windows of plain upper-case ACGT; the few windows holding anything else
+go through the reference's own chain on the host, window by window, and are merged into the sorted
+stream where the sort puts them), and k > 32 for the krisp_fasta combination (the wide path).  No CPU
+sort or k-mer generation stands in for that route when the library is missing: it raises.  What has
+no device plan is served by the plain host generator chain below; `plan_reason` says why
+(device_plan's docstring lists the cases).
 """
 import argparse
 import itertools
@@ -94,31 +96,46 @@ class kstream:
     def device_geometry(self):
         """(L, D, R) when this option set is THE krisp_fasta combination (krisp_fasta.py:21-43)."""
         plan = self.device_plan()
-        if (plan is None or plan.get("multi") or plan["strands"] != 0 or plan["layout"] != "lrd"
-                or len(plan["fields"]) != 3 or not plan["sorted"] or plan["allow"] is not None):
+        if (plan is None or plan.get("multi") or plan.get("wide") or plan["strands"] != 0 or plan["layout"] != "lrd"
+                or len(plan["fields"]) != 3 or not plan["sorted"] or plan["allow"] is not None
+                or plan["keepcase"] or plan["expand"]):
             return None
         return plan["geometry"]
 
-    def device_plan(self):
-        """How the GPU serves this option set, or None (-> the host generator chain).
+    def _no_plan(self, why):
+        self.plan_reason = why
+        return None
 
-        Accelerated: one k <= 32; both strands (complements), forward only, or canonicals; one of
-        omitsoft / mapsoft; disallow == 'Nn'; sort=True; split None, [a], [a, -b] (a, b >= 0);
-        sort columns that order the line's fields as (all fields in line order) or
-        (first, last, middle) -- GNU sort falls back to the whole line, so any column list is a
-        permutation of the fields followed by line order.  The window is packed as ONE key whose
-        unsigned order is that field order:
-          layout 'ldr'  the window as it is            -> engine geometry (k, 0, 0)
-          layout 'lrd'  first | last | middle field    -> engine geometry (first, middle, last)
-        Everything else the reference supports (allow, expand-iupac, several k, unsorted streaming,
-        other column orders, keeping lower case) stays on the host chain."""
+    def device_plan(self):
+        """How the GPU serves this option set, or None (-> the host generator chain; `plan_reason` then says why).
+
+        On the device: k <= 32 (one or several: one sort per k, the sorted streams merged); both strands (complements),
+        forward only, or canonicals; omitsoft, mapsoft or neither (lower case kept); disallow == 'Nn' (or an --allow set
+        without N); --allow of plain bases; --expand-iupac; split None, [a], [a, -b] (a, b >= 0); sorted with ANY
+        --sort-cols -- GNU sort falls back to the whole line, so a column list is a permutation of the fields followed
+        by line order, and the key holds the fields in that order (kr_set_field_order; the krisp_fasta order (first,
+        last, middle) keeps its own layout and kernels) -- or unsorted (stream order).  k > 32: the krisp_fasta
+        combination through the wide path (flanks <= 64, k <= 256).
+        The device carries windows of plain ACGT (upper case only when lower case is kept or omitted); a window holding
+        anything else that the chain would keep -- IUPAC letters, lower case under 'neither', other characters -- runs
+        through the reference's chain on the host by itself and joins the sorted stream.
+        Not on the device, with the reason in `plan_reason`:
+          * disallow sets other than 'Nn', --allow of letters beyond ACGTN, or an --allow set that both strands do not
+            share (the complement is formed before the filter);
+          * windows with N surviving (also under --expand-iupac: 4^n expansions per window);
+          * the column order (last, middle, first) of three non-empty fields whose outer widths differ: it needs two
+            different shifts of the same direction, which one key layout does not have;
+          * unsorted streams (no --sort) of several k, or of inputs that hold characters beyond ACGTN (their k-mers
+            would have to be placed by position, not by value), or with --expand-iupac / kept lower case;
+          * k > 32 outside the krisp_fasta combination, flanks > 64, k > 256."""
+        self.plan_reason = None
         if self.kmers is None or len(self.kmers) < 1:
-            return None
+            return self._no_plan("no k given: the sequences pass through as they are")
         if len(self.kmers) > 1:
             # several k: one device plan (one sort) per k, the sorted streams merged by the same
             # comparator (unsorted, the windows of every record come k by k: host chain)
             if self.sort is not True:
-                return None
+                return self._no_plan("several k without --sort: the windows of a record come k by k")
             plans = [self._plan_one(k) for k in self.kmers]
             if any(p is None for p in plans):
                 return None
@@ -126,10 +143,11 @@ class kstream:
         return self._plan_one(self.kmers[0])
 
     def _plan_one(self, k):
-        if not (1 <= k <= 32):
-            return None
-        if self.expandiupac or self.omitsoft == self.mapsoft or self.sort not in (True, False):
-            return None
+        if k < 1:
+            return self._no_plan("k < 1")
+        if self.sort not in (True, False):
+            return self._no_plan("sort must be True or False")
+        keepcase = not self.omitsoft and not self.mapsoft
         strands = 0 if self.complements else (2 if self.canonicals else 1)
         # --allow (kstream.py:696-713) of plain bases = a base mask on the device; letters the 2-bit
         # alphabet cannot carry in the allowed set (ambiguity codes, '-', ...) stay on the host chain.
@@ -137,77 +155,128 @@ class kstream:
         allow_bases = None
         if self.allow is not None:
             if not self.allow <= set("ACGTNacgtn"):
-                return None
+                return self._no_plan("--allow of letters beyond ACGTN")
             allow_bases = "".join(sorted(self.allow & set("ACGT")))
             if strands == 0 and {COMP_MAP[b] for b in allow_bases} != set(allow_bases):
-                return None
-        n_survives = self.allow is None or "N" in self.allow
+                return self._no_plan("--allow set not closed under complement while both strands are emitted")
+        n_survives = self.allow is None or "N" in self.allow or (keepcase and "n" in self.allow)
         if self.disallow != {"N", "n"} and not (self.disallow is None and not n_survives):
-            return None
+            return self._no_plan("windows holding N must be dropped (disallow 'Nn' or an --allow set without N); other disallow sets are not planned")
         # fields of the output line (kstream.py:805-832)
         if self.split is None:
             fields = [k]
         else:
             if len(self.split) not in (1, 2):
-                return None
+                return self._no_plan("more than two split points")
             a = self.split[0]
             if a < 0 or a > k:
-                return None
+                return self._no_plan("split point outside the k-mer")
             if len(self.split) == 1:
                 fields = [a, k - a]
             else:
                 b = self.split[1]
                 if b > 0 or a - b > k:
-                    return None
+                    return self._no_plan("split points outside the k-mer")
                 fields = [a, 0, k - a] if b == 0 else [a, k - a + b, -b]     # kstream.py:824-830
+        common = dict(k=k, fields=fields, strands=strands, allow=allow_bases, keepcase=keepcase, expand=self.expandiupac)
         if self.sort is False:
+            if k > 32:
+                return self._no_plan("k > 32 without --sort")
+            if keepcase or self.expandiupac:
+                return self._no_plan("unsorted stream with kept lower case / --expand-iupac: host k-mers would have to be placed by position")
             # stream order: the window as it is, cut into its fields
-            return dict(k=k, fields=fields, layout="ldr", geometry=(k, 0, 0), strands=strands, sorted=False,
-                        allow=allow_bases)
+            return dict(common, layout="ldr", order=list(range(len(fields))), geometry=(k, 0, 0), sorted=False)
         # effective order of the fields: listed columns, then line order
         cols = [] if self.sortcols is None else list(self.sortcols)
         if any((not isinstance(c, int)) or c < 0 or c >= len(fields) for c in cols):
-            return None
+            return self._no_plan("--sort-cols names a column the lines do not have")
         order = []
         for c in cols + list(range(len(fields))):
             if c not in order:
                 order.append(c)
-        order = [c for c in order if fields[c] > 0]            # empty fields do not order anything
+        live = [c for c in order if fields[c] > 0]             # empty fields do not order anything
         natural = [c for c in range(len(fields)) if fields[c] > 0]
-        if len(fields) == 3 and order == [c for c in (0, 2, 1) if fields[c] > 0]:
+        krisp_order = len(fields) == 3 and live == [c for c in (0, 2, 1) if fields[c] > 0]
+        if k > 32:
+            # amplicons longer than one key: the wide path sorts the krisp_fasta combination (krisp_fasta.py:21-43)
+            from . import _native
+            if not (krisp_order and strands == 0 and allow_bases is None and not keepcase and not self.expandiupac
+                    and self.disallow == {"N", "n"}):
+                return self._no_plan("k > 32 outside the krisp_fasta combination (complements, disallow Nn, a soft-mask rule, split [L, -R], sort columns 0 2)")
+            L, D, R = codec.effective_geometry(*fields)
+            if not (1 <= L <= _native.WIDE_MAX_FLANK and 1 <= R <= _native.WIDE_MAX_FLANK and k <= _native.WIDE_MAX_K):
+                return self._no_plan(f"k > 32 with flanks outside 1..{_native.WIDE_MAX_FLANK} or k > {_native.WIDE_MAX_K}")
+            return dict(common, wide=True, layout="lrd", order=[0, 2, 1], geometry=tuple(fields), sorted=True)
+        if krisp_order and fields[1] <= 16:
             layout, geometry = "lrd", (fields[0], fields[1], fields[2])
-        elif order == natural:
+            order = [0, 2, 1]
+        elif live == natural:
             layout, geometry = "ldr", (k, 0, 0)
+            order = list(range(len(fields)))
         else:
-            return None
-        if geometry[1] > 16:
-            return None
-        return dict(k=k, fields=fields, layout=layout, geometry=geometry, strands=strands, sorted=True,
-                    allow=allow_bases)
+            layout, geometry = "custom", (k, 0, 0)
+            order = live + [c for c in range(len(fields)) if c not in live]
+            if not codec.field_layout_ok(fields, order):
+                return self._no_plan("column order (last, middle, first) of three fields with different outer widths: two different shifts, no key layout")
+        # (--expand-iupac: windows holding N are dropped before the expansion -- the disallow / allow test above --, so an
+        # expansion is the handful of combinations of a window's other ambiguity letters)
+        return dict(common, layout=layout, order=order, geometry=geometry, sorted=True)
+
+    def _special_outputs(self, bases, plan):
+        """The k-mers of the windows the device does not carry but the chain may keep, as the reference's own chain
+        makes them (window by window, stream order: the first KeyError is the reference's): windows holding a character
+        outside ACGT -- outside ACGTacgt under mapsoft -- and none that drops the window for sure (N / n, a record
+        boundary, lower case under omitsoft).  One vectorised pass finds them; Python only runs on those windows."""
+        import numpy as np
+        k = plan["k"]
+        n = len(bases)
+        if n < k:
+            return []
+        plain = np.zeros(256, dtype=bool)
+        plain[list(b"ACGT")] = True
+        if self.mapsoft:
+            plain[list(b"acgt")] = True
+        skip = np.zeros(256, dtype=bool)
+        skip[10] = True                                   # record boundary
+        skip[list(b"Nn")] = True                          # (the plan made sure both are dropped)
+        if self.omitsoft:
+            skip[[c for c in range(256) if chr(c).islower()]] = True
+        isp = (~plain[bases]) & (~skip[bases])
+        if not isp.any():
+            return []
+        cs = np.concatenate([[0], np.cumsum(isp, dtype=np.int64)])
+        ck = np.concatenate([[0], np.cumsum(skip[bases], dtype=np.int64)])
+        starts = np.flatnonzero((cs[k:] - cs[:-k] > 0) & (ck[k:] - ck[:-k] == 0))
+        text = bases.tobytes().decode("latin-1")
+        return list(self._chain(text[i:i + k] for i in starts.tolist()))
 
     def _device_keys(self, sequences, plan):
-        """-> (sorted keys, is_rna, IUPAC k-mers as field tuples) or None when the input holds
-        characters the device alphabet cannot carry in a way only the host chain reproduces."""
+        """-> (sorted keys in the plan's field order, is_rna, host k-mers as window strings) or None when only the host
+        chain reproduces the stream (plan_reason says why)."""
+        import numpy as np
         from . import _native
         L, D, R = plan["geometry"]
-        krisp_combo = (plan["strands"] == 0 and plan["layout"] == "lrd" and len(plan["fields"]) == 3
-                       and plan["sorted"])
+        fields, order = plan["fields"], plan["order"]
+        krisp_combo = (plan["strands"] == 0 and plan["layout"] == "lrd" and len(fields) == 3 and plan["sorted"]
+                       and not plan["keepcase"] and not plan["expand"])
         allow = plan.get("allow")
         if krisp_combo:
             bases, rna, windows = fasta.ingest(sequences, plan["k"], self.omitsoft)    # (KeyError as the reference)
             # (--allow of plain bases drops every k-mer that holds an ambiguity letter)
-            special = [] if allow is not None else [codec.split_window(w, L, D, R) for w in windows]
+            special = [] if allow is not None else list(windows)
         else:
-            # forward / canonical strands, other layouts, stream order: anything outside ACGTNacgtn
-            # (IUPAC letters are kept by the reference, other characters pass or raise depending on
-            # the strand option) goes to the host chain as a whole -- unless --allow drops those
-            # k-mers anyway and no reverse complement is formed before it does
             bases, rna, nspecial = fasta.load_any(sequences)
-            if nspecial and not (allow is not None and plan["strands"] != 0):
-                return None
             special = []
+            if nspecial or plan["keepcase"]:
+                if not plan["sorted"]:
+                    self.plan_reason = "unsorted stream of an input with characters beyond ACGTN: its host k-mers would have to be placed by position"
+                    return None
+                special = self._special_outputs(bases, plan)
         with _native.Engine(device=self.device) as eng:
-            eng.set_params(L, D, R, omit_soft=self.omitsoft, max_bases=len(bases))
+            # (lower case kept: the device takes the windows without any, as under omitsoft; the others are `special`)
+            eng.set_params(L, D, R, omit_soft=self.omitsoft or plan["keepcase"], max_bases=len(bases))
+            if plan["layout"] == "custom":
+                eng.set_field_order(fields + [0] * (3 - len(fields)), order + list(range(len(fields), 3)))
             if plan["strands"]:
                 eng.set_strands(plan["strands"])
             if allow is not None:
@@ -218,6 +287,13 @@ class kstream:
             else:
                 eng.upload(0, bases)
                 keys = eng.keys_in_order(0, len(bases))
+        # host k-mers of plain ACGT (expansions of IUPAC letters) are keys like the device's
+        if special and not krisp_combo:
+            isplain = [not s.strip("ACGT") for s in special]
+            pk = codec.pack_plain([codec.order_string(s, fields, order) for s, p in zip(special, isplain) if p])
+            if len(pk):
+                keys = np.sort(np.concatenate([keys, pk]), kind="stable")
+            special = [s for s, p in zip(special, isplain) if not p]
         return keys, rna, special
 
     def _device_blocks(self, sequences, plan):
@@ -252,12 +328,31 @@ class kstream:
                 if buf:
                     yield b"\n".join(buf) + b"\n"
             return blocks(), total
+        if plan.get("wide"):
+            # k > 32, the krisp_fasta combination: the wide path's sorted-file writer (krisp_fasta.extractSortedKmers)
+            import os
+            import tempfile
+            from . import krisp_fasta as KF
+            L, _, R = plan["fields"]
+            fd, tmp = tempfile.mkstemp(prefix="kstream_wide_")
+            os.close(fd)
+            try:
+                n = KF._extract_sorted_wide(sequences, L, R, plan["k"], tmp, self.omitsoft, self.device, False)
+                with open(tmp, "rb") as f:
+                    data = f.read()
+            finally:
+                os.unlink(tmp)
+            return iter([data]), n
         got = self._device_keys(sequences, plan)
         if got is None:
             return None
         keys, rna, special = got
-        if plan["layout"] == "lrd" and len(plan["fields"]) == 3:
-            blocks = codec.merged_line_blocks(keys, special, *plan["geometry"], rna=rna, chunk=_WRITE_CHUNK)
+        if plan["layout"] == "lrd" and len(plan["fields"]) == 3 and not plan["keepcase"] and not plan["expand"] and plan["strands"] == 0 and plan["sorted"]:
+            L, D, R = plan["geometry"]
+            blocks = codec.merged_line_blocks(keys, [codec.split_window(w, L, D, R) for w in special], L, D, R, rna=rna,
+                                              chunk=_WRITE_CHUNK)
+        elif special or plan["layout"] != "ldr":
+            blocks = codec.merged_ordered_blocks(keys, special, plan["fields"], plan["order"], rna=rna, chunk=_WRITE_CHUNK)
         else:
             blocks = (codec.keys_to_fields_bytes(keys[i:i + _WRITE_CHUNK], plan["fields"], rna)
                       for i in range(0, len(keys), _WRITE_CHUNK))
@@ -280,6 +375,11 @@ class kstream:
         if self.kmers is not None:
             ks = self.kmers
             seqs = (s[i:i + k] for s in seqs for k in ks for i in range(len(s) - k + 1))
+        return self._split_all(self._chain(seqs)), rna
+
+    def _chain(self, seqs):
+        """the parsers behind the window cutter, in the reference's fixed order (kstream.py:203-235): soft mask,
+        complements, allow, disallow, expand-iupac, canonicals -- everything but the split"""
         if self.omitsoft:
             seqs = (s for s in seqs if s.isupper())
         if self.mapsoft:
@@ -296,9 +396,12 @@ class kstream:
             seqs = self._expand(seqs)
         if self.canonicals:
             seqs = (min(s, _revcomp(s)) for s in seqs)
+        return seqs
+
+    def _split_all(self, seqs):
         if self.split is not None:
             seqs = (self._split_one(s) for s in seqs)
-        return seqs, rna
+        return seqs
 
     @staticmethod
     def _expand(seqs):

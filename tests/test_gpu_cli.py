@@ -755,3 +755,79 @@ def test_bench_starts_its_own_ranks_without_a_launcher(world, tmp_path):
     assert "custom" in many["config"]["baseline_config"]
     # nothing of the launch is left behind (rendezvous files, message directories, the launcher's scratch)
     assert [p for p in os.listdir(tmp_path) if p.startswith(("krisp_comm", "krisp_bench_launch"))] == []
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_kstream_round_4_routes_equal_the_host_chain(seed, tmp_path):
+    """(f)3 of SURVEY 8: every sort-column order a key layout holds (kr_set_field_order), lower case kept, --expand-iupac,
+    IUPAC letters and stray characters under every strand mode -- the device sorts the plain windows, the others run
+    through the reference's chain on the host and are merged in -- line for line what the plain generator chain (pinned
+    to the reference by its vectors) yields, exceptions included"""
+    import itertools
+    import random
+    from krisp_amd.kstream import kstream
+    rng = random.Random(4400 + seed)
+    k = rng.choice([4, 7, 12, 21, 28, 32])
+    alphabet = "ACGT" * 10 + "acgt" * 2 + "Nn" + ("RYKMSWBDHVry" if seed % 3 else "") + ("X-" if seed % 8 == 7 else "")
+    recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 3000))) for _ in range(rng.randint(1, 4))]
+    text = "".join(f">r{i}\n{r}\n" for i, r in enumerate(recs))
+    if seed % 5 == 2:
+        text = text.replace("T", "U").replace("t", "u")
+    src = tmp_path / "g.fa"
+    src.write_text(text)
+    ran = 0
+    for trial in range(6):
+        a = rng.randint(0, k)
+        b = rng.randint(0, k - a)
+        split = rng.choice([None, [a], [a, -b], [a, -b]])
+        nf = 1 if split is None else len(split) + 1
+        cols = rng.choice([None] + [list(p) for r in range(1, nf + 1) for p in itertools.permutations(range(nf), r)])
+        kw = dict(kmers=k, disallow="Nn", sort=True)
+        kw.update(rng.choice([dict(complements=True), dict(canonicals=True), {}]))
+        kw.update(rng.choice([dict(mapsoft=True), dict(omitsoft=True), {}]))
+        if rng.random() < 0.4:
+            kw["expandiupac"] = True
+        if split is not None:
+            kw["split"] = split
+        if cols is not None:
+            kw["sortcols"] = cols
+        ks = kstream(**kw)
+        if ks.device_plan() is None:
+            assert ks.plan_reason, kw
+            continue
+        ran += 1
+
+        def run(fn):
+            try:
+                return ("ok", list(fn(str(src))))
+            except Exception as e:  # noqa: BLE001
+                return ("raises", type(e).__name__)
+        want = run(ks.host_lines)
+        assert run(ks) == want, kw
+        if want[0] == "ok":
+            out = tmp_path / "out.txt"
+            assert ks.write(str(out), str(src)) == len(want[1]), kw
+            assert out.read_text().split("\n")[:-1] == want[1], kw
+    assert ran >= 3
+
+
+@pytest.mark.parametrize("k,L,R,soft", [(33, 30, 2, "mapsoft"), (40, 16, 16, "omitsoft"), (70, 33, 20, "mapsoft"), (36, 36, 0, "mapsoft")])
+def test_kstream_longer_than_one_key_takes_the_wide_path(k, L, R, soft, tmp_path):
+    """k > 32 for the krisp_fasta combination (kstream.py:617-642 has no length limit): kr_wide_run sorts it; the same
+    lines as the host chain, also with IUPAC letters, N runs, lower case and several records"""
+    import random
+    from krisp_amd.kstream import kstream
+    rng = random.Random(k)
+    alphabet = "ACGT" * 20 + "acgt" + "N" + "R"
+    recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(20, 2500))) for _ in range(4)]
+    recs.append(recs[0][10:10 + 2 * k])                     # repeated windows: multiplicities
+    src = tmp_path / "g.fa"
+    src.write_text("".join(f">r{i}\n{r}\n" for i, r in enumerate(recs)))
+    ks = kstream(kmers=k, complements=True, disallow="Nn", split=[L, -R], sort=True, sortcols=[0, 2], **{soft: True})
+    plan = ks.device_plan()
+    assert plan is not None and plan["wide"]
+    want = list(ks.host_lines(str(src)))
+    assert len(want) > 100
+    assert list(ks(str(src))) == want
+    out = tmp_path / "o.txt"
+    assert ks.write(str(out), str(src)) == len(want) and out.read_text().split("\n")[:-1] == want

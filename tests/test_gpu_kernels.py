@@ -155,6 +155,40 @@ def test_sort_in_key_space_slices_vs_oracle(N, K, sb, n, L, D, R, omit):
     assert info["nslices"] == 4 ** min(sb, L)
 
 
+@pytest.mark.parametrize("route", [1, 0])
+@pytest.mark.parametrize("sb,n,L,D,R", [(3, 900_000, 28, 1, 2), (4, 1_500_000, 25, 1, 2), (3, 400_000, 5, 1, 2), (2, 600_000, 16, 0, 16)])
+def test_slice_pass_1_counted_from_the_codes_or_from_the_keys(N, K, route, sb, n, L, D, R, monkeypatch):
+    """round 4: a slice's pass 1 is a k_scatter2 over its pass-0 buckets whose (slice, top byte) bins were counted from the
+    codes once per genome (64 and 256 slices as configs[4] would take them; where the top 8 + 2 sb bits reach beyond
+    `left` -- L = 5 at sb = 3 -- the slice counts its keys again as in round 3); KR_SLICE_ROUTE=0 keeps round 3's route
+    everywhere: the same sorted keys either way, also for a genome with a satellite (one bin far above the 16-bit counters
+    of k_hist16) and N runs"""
+    monkeypatch.setenv("KR_SLICE_ROUTE", str(route))
+    parts = [_rand_text(500 + sb, n, alphabet=b"ACGTACGTACGTACGTNacgt", records=5), np.frombuffer(b"\n" + b"ACGTTGCA" * 12_000, dtype=np.uint8),
+             np.frombuffer(b"\n" + b"T" * 70_000, dtype=np.uint8)]
+    info = _check_sorted(N, K, np.concatenate(parts), L, D, R, slice_bases=sb)
+    assert info["nslices"] == 4 ** min(sb, L)
+
+
+@pytest.mark.parametrize("strands", [1, 2])
+def test_single_strand_modes_sort_alike_with_and_without_slices(N, strands):
+    """forward-only and canonical streams (kstream's other strand options) keep round 3's slice route (a counting pass per
+    slice) behind the pass 0 that now partitions by the slice alone: the same keys as one sort unit gives"""
+    text = _rand_text(77, 800_000, alphabet=b"ACGTACGTACGTNacgt", records=6)
+    got = []
+    for sb in (0, 2, 3):
+        with N.Engine() as e:
+            e.set_option(N.OPT_SLICE_BASES, sb)
+            e.set_params(20, 0, 0, max_bases=len(text))
+            e.set_strands(strands)
+            e.upload(0, text)
+            e.sort(0)
+            assert e.debug_info()["nslices"] == 4 ** sb
+            got.append(e.keys(0).copy())
+    assert len(got[0]) > 100_000 and np.all(got[0][1:] >= got[0][:-1])
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
 @pytest.mark.parametrize("sb,generic,fmt,kern", [(1, 0, 0, 0), (2, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (2, 1, 1, 0),
                                                  (0, 0, 0, 1), (1, 0, 1, 1), (0, 0, 0, 2), (1, 0, 1, 2), (0, 0, 2, 0)])
 @pytest.mark.parametrize("L,D,R,length,n", [(25, 1, 2, 200_000, 4), (12, 4, 12, 100_000, 3), (8, 1, 4, 20_000, 5)])

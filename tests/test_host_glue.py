@@ -107,11 +107,31 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
                    dict(split=[25], sortcols=None)):
         p = kstream(**dict(base, **change)).device_plan()
         assert p["layout"] == "ldr" and p["geometry"] == (28, 0, 0), change
-    for change in (dict(kmers=33, split=[30, -2]), dict(disallow="N"), dict(mapsoft=False),
-                   dict(expandiupac=True), dict(sortcols=[1]), dict(kmers=[28, 33]),
-                   dict(sortcols=[2]), dict(sortcols=[1, 0]), dict(split=[5, -3], sortcols=[0, 2]),
-                   dict(allow="ACGTR"), dict(allow="ACG"), dict(allow="ACGT-"), dict(kmers=[28, 29], sort=False)):
-        assert kstream(**dict(base, **change)).device_plan() is None, change
+    # round 4: every column order a key layout can hold, kept lower case, --expand-iupac, k > 32 (the wide path)
+    for change, order in ((dict(sortcols=[1]), [1, 0, 2]), (dict(sortcols=[2]), [2, 0, 1]), (dict(sortcols=[1, 0]), [1, 0, 2]),
+                          (dict(sortcols=[1, 2]), [1, 2, 0]), (dict(sortcols=[2, 0]), [2, 0, 1]),
+                          (dict(split=[5, -3], sortcols=[0, 2]), [0, 2, 1]),            # a middle field of 20 bases
+                          (dict(kmers=12, split=[5, -5], sortcols=[2, 1]), [2, 1, 0]),  # outer fields of one width
+                          (dict(split=[25], sortcols=[1]), [1, 0])):
+        p = kstream(**dict(base, **change)).device_plan()
+        assert p["layout"] == "custom" and p["order"] == order and p["geometry"][1:] == (0, 0), change
+    p = kstream(**dict(base, mapsoft=False)).device_plan()
+    assert p["keepcase"] and p["layout"] == "lrd"
+    assert kstream(**dict(base, expandiupac=True)).device_plan()["expand"]
+    p = kstream(**dict(base, kmers=33, split=[30, -2])).device_plan()
+    assert p["wide"] and p["geometry"] == (30, 1, 2)
+    assert [q.get("wide", False) for q in kstream(**dict(base, kmers=[28, 33])).device_plan()["multi"]] == [False, True]
+    # what stays on the host chain, each with its reason
+    for change, why in ((dict(disallow="N"), "must be dropped"), (dict(sortcols=[2, 1]), "two different shifts"),
+                        (dict(allow="ACGTR"), "beyond ACGTN"), (dict(allow="ACG"), "closed under complement"),
+                        (dict(allow="ACGT-"), "beyond ACGTN"), (dict(kmers=[28, 29], sort=False), "several k without --sort"),
+                        (dict(sort=False, mapsoft=False), "placed by position"), (dict(sort=False, expandiupac=True), "placed by position"),
+                        (dict(kmers=40, split=[30, -2], complements=False), "outside the krisp_fasta combination"),
+                        (dict(kmers=300, split=[30, -2]), "k > 256"), (dict(kmers=120, split=[70, -2]), "flanks outside"),
+                        (dict(kmers=40, split=[30, -2], sort=False), "k > 32 without --sort"),
+                        (dict(expandiupac=True, disallow=None), "must be dropped")):
+        ks = kstream(**dict(base, **change))
+        assert ks.device_plan() is None and why in ks.plan_reason, (change, ks.plan_reason)
     # several k (one device sort per k, merged), --allow of plain bases (a base mask), stream order
     p = kstream(**dict(base, kmers=[28, 29])).device_plan()
     assert [q["k"] for q in p["multi"]] == [28, 29]
@@ -123,6 +143,34 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     assert kstream(**dict(base, allow="ACGTN", disallow=None)).device_plan() is None       # N windows would survive
     p = kstream(**dict(base, sort=False)).device_plan()
     assert p["sorted"] is False and p["geometry"] == (28, 0, 0) and p["fields"] == [25, 1, 2]
+
+
+def test_ordered_field_codecs_place_host_kmers_where_the_sort_does():
+    """codec.merged_ordered_blocks: packed keys in any field order decoded to lines, the k-mers the device alphabet cannot
+    carry (IUPAC letters, lower case) spliced in -- against Python's sort of the same lines under the column list"""
+    import random
+    rng = random.Random(5)
+    for it in range(60):
+        fields = rng.choice([[3, 2, 4], [4, 0, 3], [2, 5], [6], [3, 3, 3], [0, 4, 2]])
+        k = sum(fields)
+        order = list(range(len(fields)))
+        rng.shuffle(order)
+        if not codec.field_layout_ok(fields, order):
+            continue
+        plain = ["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(rng.randint(0, 40))]
+        odd = ["".join(rng.choice("ACGTacgtRYn-") for _ in range(k)) for _ in range(rng.randint(0, 12))]
+        odd = [s for s in odd if s.strip("ACGT")]
+        keys = np.sort(codec.pack_plain([codec.order_string(s, fields, order) for s in plain]))
+
+        def line(s):
+            out, at = [], 0
+            for w in fields:
+                out.append(s[at:at + w])
+                at += w
+            return ",".join(out)
+        want = sorted((line(s) for s in plain + odd), key=lambda ln: tuple(ln.split(",")[c] for c in order) + (ln,))
+        got = b"".join(codec.merged_ordered_blocks(keys, odd, fields, order, chunk=7)).decode().split("\n")[:-1]
+        assert got == want, (fields, order)
 
 
 def test_codec_roundtrip_and_oracle_agreement():
