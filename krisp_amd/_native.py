@@ -539,7 +539,7 @@ class Engine:
         o = np.zeros(8, dtype=np.int64)
         self.lib.kr_debug_isect(self.ctx, _ptr(o))
         return dict(chunk_kernel_items=int(o[0]), slices_redone=int(o[1]), threads=int(o[2]), buckets_per_item_log2=int(o[3]),
-                    heads32=int(o[4]), sort_lanes=int(o[5]))
+                    heads32=int(o[4]), sort_lanes=int(o[5]), splits=int(o[6]), probed=int(o[7]))
 
     def copy_gbps(self, nbytes=1 << 30, reps=10):
         v = self.lib.kr_debug_copy_gbps(self.ctx, nbytes, reps)

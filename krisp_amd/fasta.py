@@ -74,13 +74,13 @@ def load_bases(filename):
     to_bases(read_records(filename)) through the library's one-pass host parser."""
     from . import _native
     ext = os.path.splitext(filename)[1]
-    if ext != ".bz2":
-        # read + inflate + parse inside the library (kr_ingest_file), into pinned memory
-        got = _native.ingest_file(filename)
-        if got is not None:
-            bases, _nrec, nspecial, rna, _fasta, timings = got
-            LAST_TIMINGS[os.fspath(filename)] = timings
-            return bases, bool(rna), nspecial
+    # read + inflate + parse inside the library (kr_ingest_file), into pinned memory; None: a .bz2 file on a box
+    # without libbz2
+    got = _native.ingest_file(filename)
+    if got is not None:
+        bases, _nrec, nspecial, rna, _fasta, timings = got
+        LAST_TIMINGS[os.fspath(filename)] = timings
+        return bases, bool(rna), nspecial
     if ext == ".gz":
         with gzip.open(filename, "rb") as f:
             data, universal = f.read(), False
@@ -100,12 +100,11 @@ def read_text(filename):
     (ingest_on_device)."""
     from . import _native
     ext = os.path.splitext(filename)[1]
-    if ext != ".bz2":
-        got = _native.read_file(filename)
-        if got is not None:
-            text, universal, timings = got
-            LAST_TIMINGS[os.fspath(filename)] = dict(timings, parse_s=0.0)
-            return text, universal
+    got = _native.read_file(filename)           # (None: a .bz2 file on a box without libbz2)
+    if got is not None:
+        text, universal, timings = got
+        LAST_TIMINGS[os.fspath(filename)] = dict(timings, parse_s=0.0)
+        return text, universal
     if ext == ".bz2":
         with bz2.open(filename, "rb") as f:
             return np.frombuffer(f.read(), dtype=np.uint8), False

@@ -811,7 +811,7 @@ def test_kstream_round_4_routes_equal_the_host_chain(seed, tmp_path):
     assert ran >= 3
 
 
-@pytest.mark.parametrize("k,L,R,soft", [(33, 30, 2, "mapsoft"), (40, 16, 16, "omitsoft"), (70, 33, 20, "mapsoft"), (36, 36, 0, "mapsoft")])
+@pytest.mark.parametrize("k,L,R,soft", [(33, 30, 2, "mapsoft"), (40, 16, 16, "omitsoft"), (70, 33, 20, "mapsoft"), (36, 30, 6, "mapsoft")])
 def test_kstream_longer_than_one_key_takes_the_wide_path(k, L, R, soft, tmp_path):
     """k > 32 for the krisp_fasta combination (kstream.py:617-642 has no length limit): kr_wide_run sorts it; the same
     lines as the host chain, also with IUPAC letters, N runs, lower case and several records"""

@@ -838,3 +838,50 @@ def test_intersect_right_behind_sorts_that_need_the_merge_fallback(N, K):
         assert e.debug_info()["overflow_segments"] > 0
         for i in range(3):
             assert np.array_equal(e.keys(i), want_keys[i])
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+@pytest.mark.parametrize("n,perm", [(3, [0, 2, 1]), (4, [0, 1, 2, 3]), (5, [0, 2, 1, 3, 4]), (7, [3, 0, 1, 4, 2, 5, 6]),
+                                    (8, [0, 1, 2, 3, 4, 5, 6, 7]), (4, [2, 3, 0, 1]), (6, [0, 1, 2, 3, 4, 5])])
+def test_late_genomes_probe_the_candidates_of_the_early_ones(N, K, lanes, n, perm, monkeypatch):
+    """round 4: with several sort lanes the genomes of the last round stay out of the big intersection -- it runs over
+    the early ones beside the late sorts, filtered on partial masks -- and only look the surviving candidates up
+    (k_cands_probe): candidates, masks and records equal the packed oracle's, whether the early group can prune (it holds
+    both kinds of genome) or not (then every genome takes the big intersection), for every lane count, with the sorts
+    still in flight when kr_intersect is called and again over finished sorts; KR_ISECT_SPLIT=0 gives the same"""
+    L, D, R = 25, 1, 2
+    fam = _family(60 + n, n, 300_000)
+    fam = [fam[i] for i in perm]                    # (the family's first n // 2 genomes are the ingroup: `perm` places them)
+    flags = [bool(f) for _, f, _ in fam]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
+    want = K.intersect(want_keys, flags, L, D, R, apply_filter=True)
+    wrec = np.sort(K.collect(want_keys, want, L, D, R), order=["key", "genome"])
+    assert len(want) > 10
+    for split in ("1", "0"):
+        monkeypatch.setenv("KR_ISECT_SPLIT", split)
+        with N.Engine() as e:
+            e.set_option(N.OPT_LANES, lanes)
+            e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+            for i, (_, _, t) in enumerate(fam):
+                e.upload(i, t)
+            for rep in range(2):
+                if rep == 0:
+                    for i in range(n):
+                        e.sort(i)                       # asynchronous: the intersection is called over sorts in flight
+                assert e.intersect(list(range(n)), flags, apply_filter=True) == len(want)
+                got = e.cands()
+                for f in ("prefix", "in_mask", "out_mask"):
+                    assert np.array_equal(got[f], want[f]), (f, split, rep)
+                recs = e.collect(list(range(n)))
+                assert np.array_equal(np.sort(recs, order=["key", "genome"]), wrec)
+            late = (n - 1) % lanes + 1
+            early = flags[:n - late]
+            can_split = split == "1" and n - late >= 2 and any(early) and not all(early)
+            info = e.debug_isect()
+            assert info["splits"] == (2 if can_split else 0), (info, lanes, n)
+            if can_split:
+                assert info["probed"] >= len(want)
+            # without the filter nothing is pruned: every genome takes the big intersection
+            wnf = K.intersect(want_keys, flags, L, D, R, apply_filter=False)
+            assert e.intersect(list(range(n)), flags, apply_filter=False) == len(wnf)
+            assert np.array_equal(e.cands()["prefix"], wnf["prefix"]) and e.debug_isect()["splits"] == info["splits"]

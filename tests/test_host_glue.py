@@ -677,3 +677,67 @@ def test_rendezvous_refuses_a_directory_that_is_not_private(tmp_path):
     os.chmod(base + ".rv", 0o700)
     assert D.private_dir(base + ".rv") == base + ".rv"
     assert D.rendezvous(base, 0, 1, b"x")[1] == b"x"
+
+
+def _bgzf(data, block=3000):
+    """the BGZF framing of bgzip (SAM spec 4.1): gzip members of <= 64 KiB with their length in a 'BC' extra subfield,
+    closed by the empty end-of-file member"""
+    import struct
+    import zlib
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out)
+
+
+def test_library_reads_bz2_and_block_gzip_as_python_does(tmp_path, monkeypatch):
+    """kr_read_file / kr_ingest_file on .bz2 (libbz2 through dlopen: one stream, several streams -- side by side on host
+    threads --, zero padding behind the last) and on BGZF files (members inflated side by side, with libdeflate and with
+    zlib): the text Python's bz2 / gzip modules read (kstream.py:458-479 opens both through fileinput.hook_compressed);
+    damaged files are refused, not half-read"""
+    import bz2
+    import gzip
+    from krisp_amd import _native, fasta
+    rng = np.random.default_rng(11)
+    recs = ["".join(rng.choice(list("ACGTacgtNR"), size=int(n))) for n in (5000, 1, 70_000, 333)]
+    text = "".join(f">r{i} x\n" + "\n".join(r[j:j + 60] for j in range(0, len(r), 60)) + "\n" for i, r in enumerate(recs)).encode()
+    third = len(text) // 3
+    cases = {
+        "one.fa.bz2": bz2.compress(text),
+        "multi.fa.bz2": bz2.compress(text[:third]) + bz2.compress(text[third:2 * third]) + bz2.compress(text[2 * third:]),
+        "padded.fa.bz2": bz2.compress(text) + b"\0" * 7,
+        "block.fa.gz": _bgzf(text),
+        "plain.fa.gz": gzip.compress(text),
+    }
+    want_bases = fasta.to_bases(fasta.read_records(text.split(b"\n")[:-1]))
+    for threads in ("4", "1"):
+        monkeypatch.setenv("KRISP_INGEST_THREADS", threads)
+        for nold in ("", "1"):
+            if nold:
+                monkeypatch.setenv("KRISP_NO_LIBDEFLATE", "1")      # (read when the library first inflates: only a fresh process sees it)
+            for name, blob in cases.items():
+                p = tmp_path / name
+                p.write_bytes(blob)
+                got = _native.read_file(str(p))
+                assert got is not None, name
+                arr, universal, timings = got
+                assert arr.tobytes() == text and not universal, name
+                if name == "multi.fa.bz2":
+                    assert timings["members"] == 3
+                if name == "block.fa.gz":
+                    assert timings["members"] == len(text) // 3000 + 2
+                bases, nrec, nspecial, rna, is_fasta, _t = _native.ingest_file(str(p))
+                assert bases.tobytes() == want_bases.tobytes() and nrec == 4 and is_fasta and not rna and nspecial > 0
+                # the host layer's reader takes the same route
+                assert fasta.load_bases(str(p))[0].tobytes() == want_bases.tobytes()
+    for name, blob in (("cut.fa.bz2", cases["one.fa.bz2"][:-9]), ("junk.fa.bz2", b"BZh9" + b"\x31\x41\x59\x26\x53\x59" + b"x" * 40),
+                       ("cutblock.fa.gz", cases["block.fa.gz"][:-40]), ("tail.fa.bz2", cases["one.fa.bz2"] + b"tail")):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        with pytest.raises(_native.KrispHipError):
+            _native.read_file(str(p))
