@@ -220,6 +220,12 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
                                    rights present in every genome are the reverse complements of the lefts, and a right
                                    takes the number of that left */
 int64_t kr_wide_fetch(kr_ctx*, int what, void* out, size_t cap_bytes);   /* returns #elements; out == NULL: size query */
+/* The member windows of the latest kr_wide_run as text, cut on the device from the genomes' uploaded bases: row i = the
+ * L+D+R letters of hit i (KR_WIDE_HITS order) in line order left|diag|right, upper case, the reverse complement for a
+ * strand-1 member -- what the reference writes as one line of its merged file (Amplicon.py:330-348), so the host needs no
+ * copy of the genomes to render long amplicons (kr_render_windows).  One context (no communicator of more than one
+ * rank: the hits of other ranks' genomes have no bases here).  Returns the number of rows; rows == NULL: size query. */
+int64_t kr_wide_fetch_windows(kr_ctx*, uint8_t* rows, size_t cap_bytes);
 
 /* Host-side ingest (no GPU involved): the text of a FASTA / sequence-per-line file -> the
  * upload buffer of kr_genome_upload, with the reference reader's semantics
@@ -275,6 +281,14 @@ int64_t kr_scan_special(const uint8_t* bases, size_t n, int k, int omit_soft, ui
 int64_t kr_render_records(const kr_record* recs, size_t n, int L, int D, int R, const uint32_t* label_of,
                           size_t n_genomes, const char* const* label_text, size_t n_labels, const uint8_t* label_in,
                           int dot, char** csv, size_t* csv_len, char** align, size_t* align_len);
+/* ... and from member windows of long amplicons (kr_wide_fetch_windows; Amplicon.py:598-671 on text the reference holds as
+ * strings anyway): rows = n windows of L+D+R letters in line order, cand[i] = group number of row i (the rows of a group
+ * adjacent: KR_WIDE_HITS order), genome[i] = index into label_of.  Groups are ordered by (left, right), members by (diag,
+ * label) here.  rna: write T as U.  KR_ERR_HOST also when one (left,right) arrives under two group numbers. */
+int64_t kr_render_windows(const uint8_t* rows, size_t n, int L, int D, int R, const uint32_t* cand, const uint32_t* genome,
+                          const uint32_t* label_of, size_t n_genomes, const char* const* label_text, size_t n_labels,
+                          const uint8_t* label_in, int dot, int rna, char** csv, size_t* csv_len, char** align,
+                          size_t* align_len);
 void    kr_text_free(void* p);
 
 /* Options that change HOW (never what) the library computes; results are identical for every

@@ -82,6 +82,9 @@ SYMBOLS = [
     ("kr_set_params_wide", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_size_t]),
     ("kr_wide_run", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_wide_fetch", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
+    ("kr_wide_fetch_windows", _c.c_int64, [_P, _P, _c.c_size_t]),
+    ("kr_render_windows", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P, _c.c_size_t, _P,
+                                       _c.c_int, _c.c_int, _P, _P, _P, _P]),
     ("kr_fasta_to_bases", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
     ("kr_ingest_file", _c.c_int64, [_c.c_char_p, _P, _P]),
     ("kr_read_file", _c.c_int64, [_c.c_char_p, _P, _P]),
@@ -238,6 +241,36 @@ def render_records(records, label_of, label_text, label_in, L, D, R, dot=False):
         return None
     if rc < 0:
         raise KrispHipError(f"kr_render_records: [{rc}]")
+    try:
+        return (_c.string_at(csv, ncsv.value).decode("utf-8", "surrogateescape"),
+                _c.string_at(align, nalign.value).decode("utf-8", "surrogateescape"), int(rc))
+    finally:
+        lib.kr_text_free(csv)
+        lib.kr_text_free(align)
+
+
+def render_windows(rows, cand, genome, label_of, label_text, label_in, L, D, R, dot=False, rna=False):
+    """kr_render_windows: (csv_text, alignment_text, number of groups) from the member windows of long amplicons (rows:
+    uint8 [n, L+D+R] in line order, cand / genome per row as kr_wide_fetch(HITS) gives them), or None when the library
+    leaves a group to the general path"""
+    lib = load()
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    cand = np.ascontiguousarray(cand, dtype=np.uint32)
+    gen = np.ascontiguousarray(genome, dtype=np.uint32)
+    lof = np.ascontiguousarray(label_of, dtype=np.uint32)
+    texts = [t.encode("utf-8", "surrogateescape") for t in label_text]
+    arr = (_c.c_char_p * max(len(texts), 1))(*texts)
+    lin = None if label_in is None else np.ascontiguousarray(label_in, dtype=np.uint8)
+    csv, align = _c.c_void_p(), _c.c_void_p()
+    ncsv, nalign = _c.c_size_t(), _c.c_size_t()
+    rc = lib.kr_render_windows(_ptr(rows) if len(rows) else None, len(rows), L, D, R, _ptr(cand) if len(rows) else None,
+                               _ptr(gen) if len(rows) else None, _ptr(lof), len(lof), arr, len(texts),
+                               None if lin is None else _ptr(lin), 1 if dot else 0, 1 if rna else 0, _c.byref(csv),
+                               _c.byref(ncsv), _c.byref(align), _c.byref(nalign))
+    if rc == ERR_HOST:
+        return None
+    if rc < 0:
+        raise KrispHipError(f"kr_render_windows: [{rc}]")
     try:
         return (_c.string_at(csv, ncsv.value).decode("utf-8", "surrogateescape"),
                 _c.string_at(align, nalign.value).decode("utf-8", "surrogateescape"), int(rc))
@@ -496,6 +529,13 @@ class Engine:
         n = self._check(self.lib.kr_wide_fetch(self.ctx, what, None, 0), "kr_wide_fetch")
         out = np.empty(max(n, 1), dtype=WIDE_HIT if what == WIDE_HITS else np.uint64)
         self._check(self.lib.kr_wide_fetch(self.ctx, what, _ptr(out), out.nbytes), "kr_wide_fetch")
+        return out[:n]
+
+    def wide_windows(self, k):
+        """the member windows of the latest wide_run as text, cut on the device (kr_wide_fetch_windows): uint8 [nhits, k]"""
+        n = self._check(self.lib.kr_wide_fetch_windows(self.ctx, None, 0), "kr_wide_fetch_windows")
+        out = np.empty((max(n, 1), k), dtype=np.uint8)
+        self._check(self.lib.kr_wide_fetch_windows(self.ctx, _ptr(out), out.nbytes), "kr_wide_fetch_windows")
         return out[:n]
 
     # ---- timing

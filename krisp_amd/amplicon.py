@@ -130,6 +130,83 @@ class RecordGroups:
         return None if out is None else (out[0], out[1])
 
 
+class WindowGroups:
+    """The surviving groups of amplicons longer than one key as the device left them -- the member windows as text rows
+    (kr_wide_fetch_windows), their group numbers and genomes -- behind the interface of the list of groups.  render()
+    turns it into text in the library (kr_render_windows: groups ordered by (left, right), members by (diag, label),
+    no object per Amplicon: configs[2] with close relatives yields > 10^5 groups); whoever walks the groups gets the
+    list, built on first use."""
+
+    def __init__(self, rows, cand, genome, labels, L, D, R, rna=False):
+        self.rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        self.cand = np.ascontiguousarray(cand, dtype=np.uint32)
+        self.genome = np.ascontiguousarray(genome, dtype=np.uint32)
+        self.labels, self.L, self.D, self.R, self.rna = list(labels), L, D, R, bool(rna)
+        self._groups = None
+        self._n = int(len(np.unique(self.cand)))
+
+    def groups(self):
+        if self._groups is None:
+            self._groups = groups_from_windows(self.rows, self.genome, self.labels, self.L, self.D, self.R)
+            if self.rna:
+                for g in self._groups:
+                    for a in g:
+                        a.left, a.diag, a.right = (x.replace("T", "U") for x in (a.left, a.diag, a.right))
+        return self._groups
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self.groups())
+
+    def __getitem__(self, i):
+        return self.groups()[i]
+
+    def render_text(self, ingroup_labels, dot=False):
+        """-> (csv, alignment) through the library, or None when it leaves a group to the general path"""
+        from . import _native
+        distinct = sorted(set(self.labels))
+        rank = {t: i for i, t in enumerate(distinct)}
+        label_of = np.array([rank[t] for t in self.labels], dtype=np.uint32)
+        label_in = None if ingroup_labels is None else np.array([1 if t in ingroup_labels else 0 for t in distinct],
+                                                                dtype=np.uint8)
+        out = _native.render_windows(self.rows, self.cand, self.genome, label_of, distinct, label_in, self.L, self.D,
+                                     self.R, dot, self.rna)
+        return None if out is None else (out[0], out[1])
+
+
+def groups_from_windows(rows, genome, labels, L, D, R):
+    """member windows as text rows (uint8 [n, L+D+R], line order) + the genome of each -> groups of Amplicon in the
+    reference's order: groups by (left, right), sequences by diag, labels sorted (the general path of long amplicons)"""
+    if len(rows) == 0:
+        return []
+    k = L + D + R
+    row = np.empty((len(rows), k + 4), dtype=np.uint8)
+    row[:, 0:L] = rows[:, :L]
+    row[:, L:L + R] = rows[:, L + D:]
+    row[:, L + R:k] = rows[:, L:L + D]
+    row[:, k:] = np.asarray(genome).astype(">u4").view(np.uint8).reshape(-1, 4)
+    uniq, counts = np.unique(row, axis=0, return_counts=True)
+    groups, last_cand, last_seq = [], None, None
+    for r, cnt in zip(uniq, counts):
+        cand = bytes(r[0:L + R])
+        seq = bytes(r[0:k])
+        gi = int.from_bytes(bytes(r[k:]), "big")
+        if cand != last_cand:
+            groups.append([])
+            last_cand, last_seq = cand, None
+        if seq != last_seq:
+            txt = seq.decode("ascii")
+            groups[-1].append(Amplicon(txt[:L], txt[L + R:], txt[L:L + R], []))
+            last_seq = seq
+        groups[-1][-1].labels.extend([labels[gi]] * int(cnt))
+    for g in groups:
+        for a in g:
+            a.labels.sort()
+    return groups
+
+
 def groups_from_records(records, labels, L, D, R, rna=False):
     """(key, genome, count) records of the survivors -> list of groups (lists of
     Amplicon), groups ascending by (left,right), Amplicons ascending by diag --
@@ -255,7 +332,7 @@ def render(groups, ingroup_labels, dot=False):
     (outputAlignments.py:101-162): header, one row / block per group; each block is
     print()ed, hence the blank line after it."""
     ingroup = None if ingroup_labels is None else frozenset(ingroup_labels)
-    if isinstance(groups, RecordGroups):
+    if isinstance(groups, (RecordGroups, WindowGroups)):
         text = groups.render_text(ingroup, dot)
         if text is not None:
             return text

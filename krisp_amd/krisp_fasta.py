@@ -409,11 +409,17 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             if verbose:
                 for f, cnt in zip(files, counts):
                     print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)
-            groups = _groups_from_hits(hits, texts, labels, Le, De, Re)
             if touched:
+                groups = _groups_from_hits(hits, texts, labels, Le, De, Re)
                 sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text,
                                                (Le, De, Re), ingroup_labels, do_filter)
                 groups = _merge_groups(groups, touched, sgroups)
+            else:
+                # the member windows are cut on the device (kr_wide_fetch_windows) and rendered from their rows in the
+                # library (amplicon.WindowGroups: no object per window; the list of groups only if someone walks it)
+                rows = eng.wide_windows(k) if nhits else np.empty((0, k), dtype=np.uint8)
+                groups = amplicon.WindowGroups(rows, hits["cand"], hits["genome"], labels, Le, De, Re, rna=all(rna))
+                finish = lambda g: g        # noqa: E731  (the RNA letters are the renderer's)
         stats.update(device_s=time.time() - t1, kmers=int(sum(counts)) + sum(len(sp) for sp in specials),
                      candidates=ngroups)
         return finish(groups), stats

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "krisp_hip.h"
@@ -120,6 +121,64 @@ int main() {
                                   &al, &na) != KR_ERR_PARAM) return 9;
         }
     }
-    printf("ASAN_HOST_OK %ld scans %ld renders\n", checks, renders);
+    // kr_render_windows: window rows of random geometry (flanks beyond 32 letters too), group numbers in any order, the rows of
+    // a group interleaved with its neighbours', one (left,right) under two numbers (declined), a genome out of range
+    long wrenders = 0;
+    for (int it = 0; it < 300; it++) {
+        const int L = 1 + rnd() % 40, D = rnd() % 20, R = 1 + rnd() % 40, k = L + D + R;
+        const uint32_t ngen = 1 + rnd() % 5, nlab = 1 + rnd() % ngen;
+        std::vector<uint32_t> label_of(ngen);
+        for (auto& l : label_of) l = rnd() % nlab;
+        std::vector<std::string> names(nlab);
+        std::vector<const char*> text(nlab);
+        for (size_t i = 0; i < nlab; i++) { names[i] = "w" + std::to_string(i); text[i] = names[i].c_str(); }
+        std::vector<uint8_t> is_in(nlab);
+        for (auto& v : is_in) v = rnd() & 1;
+        const int ngroups = rnd() % 6;
+        std::vector<uint8_t> rows;
+        std::vector<uint32_t> cand, gen;
+        for (int g = 0; g < ngroups; g++) {
+            std::string fl(k, 'A');
+            for (int q = 0; q < k; q++) fl[q] = "ACGT"[rnd() & 3];
+            fl[0] = "ACGT"[g & 3];                          // (distinct flanks per group, mostly)
+            if (L > 1) fl[1] = "ACGT"[(g >> 2) & 3];
+            const int nm = 1 + rnd() % 6;
+            for (int m = 0; m < nm; m++) {
+                std::string w = fl;
+                for (int q = L; q < L + D; q++) w[q] = "ACGT"[rnd() & 3];
+                rows.insert(rows.end(), w.begin(), w.end());
+                cand.push_back((uint32_t)g | ((rnd() & 7) == 0 ? 0u : 0u));
+                gen.push_back(rnd() % ngen);
+            }
+        }
+        // interleave: swap random rows (the renderer orders by group number itself)
+        const size_t n = cand.size();
+        for (size_t q = 0; q + 1 < n; q++) {
+            const size_t o = q + rnd() % (n - q);
+            std::swap(cand[q], cand[o]);
+            std::swap(gen[q], gen[o]);
+            for (int b = 0; b < k; b++) std::swap(rows[q * k + b], rows[o * k + b]);
+        }
+        for (int with_in = 0; with_in < 2; with_in++)
+            for (int dot = 0; dot < 2; dot++) {
+                char *csv = nullptr, *al = nullptr;
+                size_t nc = 0, na = 0;
+                const int64_t r = kr_render_windows(rows.data(), n, L, D, R, cand.data(), gen.data(), label_of.data(), ngen, text.data(),
+                                                    nlab, with_in ? is_in.data() : nullptr, dot, it & 1, &csv, &nc, &al, &na);
+                if (r < 0 && r != KR_ERR_HOST) { printf("window render failed %lld\n", (long long)r); return 10; }
+                if (r >= 0 && (nc < 28 || csv[nc - 1] != '\n')) return 11;
+                kr_text_free(csv);
+                kr_text_free(al);
+                wrenders++;
+            }
+        if (n) {
+            gen[0] = 1000;
+            char *csv = nullptr, *al = nullptr;
+            size_t nc = 0, na = 0;
+            if (kr_render_windows(rows.data(), n, L, D, R, cand.data(), gen.data(), label_of.data(), ngen, text.data(), nlab, nullptr, 0, 0,
+                                  &csv, &nc, &al, &na) != KR_ERR_PARAM) return 12;
+        }
+    }
+    printf("ASAN_HOST_OK %ld scans %ld renders %ld window renders\n", checks, renders, wrenders);
     return 0;
 }

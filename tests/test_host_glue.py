@@ -428,7 +428,8 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
     """The library's kernels keep everything in registers and LDS: a private array indexed at run time or
     spilled registers show as `ScratchSize` in hipcc's resource remarks -- and have crept in unnoticed through an
     unrelated edit (spilled scalar registers in k_hist8w<2>, round 3).  Cross-compiles the translation unit (no GPU
-    needed) and reads the remarks."""
+    needed) and reads the remarks: no scratch, no spilled vector registers, and a bound on the scalar registers a
+    kernel parks in vector lanes."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -440,7 +441,7 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
                         "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    name, bad, seen = None, [], 0
+    name, bad, seen, spills = None, [], 0, {}
     for line in r.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
@@ -450,8 +451,19 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
             seen += 1
             if int(m.group(1)):
                 bad.append((name, int(m.group(1))))
+        m = re.search(r"SGPRs Spill: (\d+)", line)
+        if m and int(m.group(1)):
+            spills[name] = int(m.group(1))
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and int(m.group(1)):
+            bad.append((name, "VGPR spill", int(m.group(1))))
     assert seen > 50, "no resource remarks: has the flag changed?"
     assert not bad, bad
+    # scalar registers spilled to vector lanes cost no memory traffic, but hundreds of them (round 3: 200-280 in the wide
+    # path's kernels, which took the dictionaries of both flanks by value) mean the kernel's arguments do not fit the
+    # register file: SGPR_SPILL_BOUND is what the largest argument lists left are allowed
+    SGPR_SPILL_BOUND = 64
+    assert all(v <= SGPR_SPILL_BOUND for v in spills.values()), spills
 
 
 def test_scan_special_through_the_abi_equals_the_python_scan():
@@ -503,7 +515,7 @@ def test_text_code_under_address_sanitizer(tmp_path):
     exe = str(tmp_path / "asan_host")
     src = os.path.join(ROOT, "tests", "native", "asan_host.cpp")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-I" + os.path.join(ROOT, "include"), "-o", exe, src])
+                           "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe, src])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ASAN_HOST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
@@ -741,3 +753,52 @@ def test_library_reads_bz2_and_block_gzip_as_python_does(tmp_path, monkeypatch):
         p.write_bytes(blob)
         with pytest.raises(_native.KrispHipError):
             _native.read_file(str(p))
+
+
+def test_window_renderer_equals_the_general_path():
+    """kr_render_windows (the member windows of long amplicons as text rows -> CSV + alignment bytes, groups ordered by
+    (left, right), members by (diag, label), pieces rendered side by side) against amplicon.render over
+    groups_from_windows -- the restatement of Amplicon.py:523-671 the long-amplicon goldens pin: random geometries with
+    flanks beyond one key, interleaved rows, mirror group numbers, label collisions, RNA, both alignment forms, the
+    cases where the reference raises (declined), and 4 x 10^4 groups through the threaded pieces"""
+    from krisp_amd import amplicon
+    rng = np.random.default_rng(17)
+    same = declined = 0
+    for it in range(260):
+        big = it == 0
+        L, D, R = int(rng.integers(1, 45)), int(rng.integers(0, 30)), int(rng.integers(1, 45))
+        k = L + D + R
+        ng = 40_000 if big else int(rng.integers(1, 9))
+        nl = int(rng.integers(1, 6))
+        labels = [f"g{c}" for c in rng.permutation(nl)]
+        if it % 5 == 0 and nl > 1:
+            labels[1] = labels[0]
+        flanks = np.unique(rng.integers(0, 4, size=(ng, L + R)), axis=0)
+        rows, cand, gen = [], [], []
+        for gi, fl in enumerate(flanks):
+            nd = 1 if D == 0 else int(rng.integers(1, 4))
+            diags = rng.integers(0, 4, size=(nd, D))
+            for d in diags:
+                for g in rng.choice(nl, size=int(rng.integers(1, nl + 1)), replace=False):
+                    for _rep in range(int(rng.integers(1, 3))):
+                        rows.append(np.concatenate([fl[:L], d, fl[L:]]))
+                        cand.append(gi | (0x80000000 if gi % 3 == 0 else 0))
+                        gen.append(int(g))
+        rows = np.frombuffer(b"ACGT", dtype=np.uint8)[np.array(rows)]
+        perm = rng.permutation(len(rows))
+        rows, cand, gen = rows[perm], np.array(cand, dtype=np.uint32)[perm], np.array(gen, dtype=np.uint32)[perm]
+        ingroup = None if it % 3 == 0 else frozenset(labels[:max(1, nl // 2)])
+        rna = it % 7 == 3
+        for dot in (False, True):
+            wg = amplicon.WindowGroups(rows, cand, gen, labels, L, D, R, rna=rna)
+            general = amplicon.WindowGroups(rows, cand, gen, labels, L, D, R, rna=rna).groups()
+            assert len(wg) == len(general)
+            try:
+                want = amplicon.render(general, ingroup, dot)
+            except (ValueError, KeyError):
+                assert wg.render_text(ingroup, dot) is None
+                declined += 1
+                continue
+            assert amplicon.render(wg, ingroup, dot) == want, (L, D, R, labels, ingroup, dot)
+            same += 1
+    assert same > 250 and declined > 20
