@@ -81,7 +81,12 @@ def _read(path):
 def _write_atomic(path, data):
     """a reader never sees a partial file; the temporary name is ours alone (O_EXCL, mode 0600)"""
     tmp = f"{path}.{os.getpid()}.{secrets.token_hex(4)}.tmp"
-    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    try:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    except FileNotFoundError:
+        # (the directory went away under us: rank 0 of an earlier run under the same name has just tidied up)
+        private_dir(os.path.dirname(path))
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
     with os.fdopen(fd, "wb") as f:
         f.write(data)
     os.replace(tmp, path)

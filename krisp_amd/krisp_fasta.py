@@ -221,32 +221,36 @@ def _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter):
     return groups
 
 
-def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, geo, ingroup, do_filter):
-    """Wide-path twin of _special_groups.  A touched (left,right) pair with an IUPAC letter in a
-    flank can only hold IUPAC k-mers (the host has them all); a pair with plain flanks also
-    holds ACGT windows, which the device locates: one kr_wide_run per genome against a probe
-    genome made of the touched pairs (left + A..A + right) returns every window of that genome
-    whose flanks are one of them."""
+def _wide_probe_members(eng, texts, gis, probes, probe_text, geo, pid):
+    """the ACGT members of the touched (left,right) pairs with plain flanks in the genomes gis (texts[i] = genome gis[i]):
+    one kr_wide_run per genome against a probe genome made of the pairs (left + A..A + right) returns every window of
+    that genome whose flanks are one of them.  -> {(left,right): {(left,diag,right): {genome: count}}}"""
     from . import _native
     L, D, R = geo
-    n = len(texts)
-    members = {}            # (left,right) -> {(left,diag,right) -> {genome index -> count}}
-    if probes:
-        wanted = set(probes)
-        pid = n             # genome id of the probe
-        eng.upload(pid, probe_text)
-        for gi in range(n):
-            nh = eng.wide_run([pid, gi], [True, True], apply_filter=False)
-            if not nh:
-                continue
-            hits = eng.wide_fetch(_native.WIDE_HITS)
-            hits = hits[hits["genome"] == 1].copy()
-            hits["genome"] = 0
-            for g in _groups_from_hits(hits, [texts[gi]], ["x"], L, D, R):
-                for a in g:
-                    if (a.left, a.right) in wanted:
-                        m = members.setdefault((a.left, a.right), {}).setdefault((a.left, a.diag, a.right), {})
-                        m[gi] = m.get(gi, 0) + len(a.labels)
+    members = {}
+    if not probes:
+        return members
+    wanted = set(probes)
+    eng.upload(pid, probe_text)
+    for gi, text in zip(gis, texts):
+        nh = eng.wide_run([pid, gi], [True, True], apply_filter=False)
+        if not nh:
+            continue
+        hits = eng.wide_fetch(_native.WIDE_HITS)
+        hits = hits[hits["genome"] == 1].copy()
+        hits["genome"] = 0
+        for g in _groups_from_hits(hits, [text], ["x"], L, D, R):
+            for a in g:
+                if (a.left, a.right) in wanted:
+                    m = members.setdefault((a.left, a.right), {}).setdefault((a.left, a.diag, a.right), {})
+                    m[gi] = m.get(gi, 0) + len(a.labels)
+    return members
+
+
+def _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do_filter):
+    """the groups IUPAC windows touch, from the ACGT members the device found (_wide_probe_members, of one context or
+    merged over the ranks) and the IUPAC members themselves (specials[g] of genome g), under the reference's rules:
+    present in every genome (intersectAmplicons.py:232-310), an ingroup-unique column (Amplicon.py:495-521)"""
     for gi, sp in enumerate(specials):
         for (l, d, r) in sp:
             m = members.setdefault((l, r), {}).setdefault((l, d, r), {})
@@ -264,13 +268,22 @@ def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_te
         group = []
         for seq in sorted(seqs, key=lambda t: t[1]):
             labs = []
-            for gi, cnt in seqs[seq].items():
+            for gi, cnt in sorted(seqs[seq].items()):
                 labs += [labels[gi]] * cnt
-            group.append(amplicon.Amplicon(seq[0], seq[1], seq[2], labs))
+            group.append(amplicon.Amplicon(seq[0], seq[1], seq[2], sorted(labs)))
         if do_filter and not amplicon.ingroup_unique_columns(group, ingroup):
             continue
         groups.append(group)
     return groups
+
+
+def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, geo, ingroup, do_filter):
+    """Wide-path twin of _special_groups.  A touched (left,right) pair with an IUPAC letter in a
+    flank can only hold IUPAC k-mers (the host has them all); a pair with plain flanks also
+    holds ACGT windows, which the device locates (_wide_probe_members)."""
+    n = len(texts)
+    members = _wide_probe_members(eng, texts, list(range(n)), probes, probe_text, geo, pid=n)
+    return _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do_filter)
 
 
 def _merge_groups(device_groups, touched, special_groups):
@@ -514,9 +527,6 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         if kinds[1] and kinds[3]:
             raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
         all_rna = bool(kinds[1])
-        if kinds[0] and wide:
-            raise fasta.IupacWindowsUnsupported("IUPAC ambiguity letters inside long amplicons: run on one GPU (their "
-                                                "groups are rebuilt through probe genomes there)")
         # windows with IUPAC letters (kept by the reference, kstream.py:11-18; the device alphabet cannot carry them):
         # every rank learns all of them -- they are rare --, the groups they touch are rebuilt on rank 0 from the
         # ranks' device look-ups of the ACGT members (below), as find_regions does on one GPU
@@ -550,6 +560,36 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
 
             nh, counts, ngroups = together(wide_part)
             hits = eng.wide_fetch(_native.WIDE_HITS) if (rank == 0 and nh) else np.empty(0, dtype=_native.WIDE_HIT)
+            # windows with IUPAC letters (round 4; one GPU only before): every rank knows all of them (specials_all), so
+            # every rank derives the same touched (left,right) pairs and the same probe genome, looks the pairs' ACGT
+            # members up in ITS genomes -- a context of its own without a communicator: the look-ups are local, one
+            # kr_wide_run per genome -- and rank 0 gets everybody's findings and rebuilds the touched groups
+            wide_sp = None
+            if specials_all is not None:
+                import json
+                touched_w = {(l, r) for sp in specials_all for (l, d, r) in sp}
+                probes = sorted(p for p in touched_w if _pure(p[0]) and _pure(p[1]))
+                probe_text = np.frombuffer("\n".join(l + "A" * De + r for l, r in probes).encode(), dtype=np.uint8)
+
+                def probe_part():
+                    if not probes:
+                        return {}
+                    with _native.Engine(device=device) as e2:
+                        e2.set_params_wide(Le, De, Re, omit_soft=omit_soft, max_bases=max(int(kinds[2]), len(probe_text)))
+                        for g, (bases, _, _) in zip(mine, loaded):
+                            e2.upload(g, bases)
+                        return _wide_probe_members(e2, [b for b, _, _ in loaded], list(mine), probes, probe_text,
+                                                   (Le, De, Re), pid=len(order))
+
+                local = together(probe_part)
+                flat = [[list(P), list(seq), int(g), int(cnt)] for P, seqs in local.items() for seq, m in seqs.items()
+                        for g, cnt in m.items()]
+                members_w = {}
+                for blob in eng.comm_allgather(json.dumps(flat).encode()):
+                    for P, seq, g, cnt in json.loads(blob.decode()):
+                        m = members_w.setdefault(tuple(P), {}).setdefault(tuple(seq), {})
+                        m[g] = m.get(g, 0) + cnt
+                wide_sp = (touched_w, members_w)
             eng.comm_barrier()
             stats.update(device_s=time.time() - t1, kmers=counts, candidates=ngroups, records=int(len(hits)))
             if rank != 0:
@@ -562,6 +602,10 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
                 if texts[g] is None:
                     texts[g] = fasta.ingest(order[g], k, omit_soft)[0]
             wg = _groups_from_hits(hits, texts, labels, Le, De, Re)
+            if wide_sp is not None:
+                touched_w, members_w = wide_sp
+                sg = _special_groups_wide_from(members_w, len(order), labels, specials_all, touched_w, ingroup_labels, do_filter)
+                wg = _merge_groups(wg, touched_w, sg)
             return (_to_rna(wg) if all_rna else wg), stats
 
         def device_part():

@@ -158,7 +158,7 @@ def test_rendezvous_ignores_what_a_crashed_run_left(tmp_path):
     import threading
     from krisp_amd import distributed as D
     base = str(tmp_path / "rv")
-    os.makedirs(base + ".rv")
+    os.makedirs(base + ".rv", mode=0o700)              # (as the crashed run made it: private to this user)
     for r in (1, 2):
         open(os.path.join(base + ".rv", f"join_{r}"), "wb").write(b"0123456789abcdef")
         open(os.path.join(base + ".rv", f"go_{r}"), "wb").write(b"0123456789abcdef" + b"f" * 16 + b"stale payload")
@@ -177,4 +177,4 @@ def test_rendezvous_ignores_what_a_crashed_run_left(tmp_path):
         assert all(o is not None for o in out)
         assert {o[1] for o in out} == {b"payload of rank 0"}
         assert len({o[0] for o in out}) == 1 and out[0][0] != "f" * 16
-    assert os.listdir(base + ".rv") == []
+    assert not os.path.exists(base + ".rv")             # (rank 0 takes the files and the directory away)

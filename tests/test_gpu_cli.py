@@ -831,3 +831,42 @@ def test_kstream_longer_than_one_key_takes_the_wide_path(k, L, R, soft, tmp_path
     assert list(ks(str(src))) == want
     out = tmp_path / "o.txt"
     assert ks.write(str(out), str(src)) == len(want) and out.read_text().split("\n")[:-1] == want
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_iupac_letters_in_long_amplicons_over_several_ranks(seed, tmp_path):
+    """round 4: amplicons longer than one key whose windows hold IUPAC ambiguity letters no longer ask for one GPU: every
+    rank learns all such windows, probes ITS genomes for the ACGT members of the (left,right) pairs they touch (a context
+    of its own, no communicator) and rank 0 rebuilds those groups -- two or three ranks sharing the GPU against the text
+    oracle's stages and the one-GPU flow, RNA input included"""
+    import random
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    from oracle import krisp_oracle as O
+    rng = random.Random(9100 + seed)
+    L, D, R = rng.choice([(12, 14, 10), (20, 0, 15), (8, 20, 8), (17, 3, 17)])
+    rna = seed % 3 == 2
+    n_in, n_out = 2, rng.randint(1, 2)
+    anc = "".join(rng.choice("ACGT") for _ in range(rng.randint(300, 900)))
+    ing, outg = [], []
+    for gi in range(n_in + n_out):
+        s = list(anc)
+        for _ in range(rng.randint(0, 5)):
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        for _ in range(rng.randint(1, 4)):
+            s[rng.randrange(len(s))] = rng.choice("RYKMSWryn")
+        text = "".join(s)
+        if rna:
+            text = text.replace("T", "U").replace("t", "u")
+        p = tmp_path / f"{'in' if gi < n_in else 'out'}{gi}.fa"
+        p.write_text(">r\n" + text + "\n")
+        (ing if gi < n_in else outg).append(str(p))
+    k = L + D + R
+    sf = [(f"{O.basename(f)}.{k}mers", O.extract_sorted_kmers(f, L, R, k, False)) for f in ing + outg]
+    merged = O.merge_tree(sf)
+    expect = O.filter_lines(merged, [O.simplename(f) for f in ing]) if D > 0 else merged
+    one, _ = KF.find_regions(ing, outg, L, R, k)
+    assert sorted(amplicon.merged_lines(one)) == sorted(expect)
+    devices = [0] * (2 if seed % 2 == 0 else 3)
+    groups, _ = KF.find_regions_multi_device(ing, outg, L, R, k, devices)
+    assert sorted(amplicon.merged_lines(groups)) == sorted(expect)

@@ -7,7 +7,7 @@
 #   profiles/traffic.json                HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE)
 # Everything is written under gpurun_out/<round>/ (merged back by gpurun); copy into profiles/ afterwards.
 set -e
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"

@@ -2,7 +2,7 @@
 # One bench line per BASELINE.json config (bench.py --config N: the label comes from the table, not from a guess) and
 # for SURVEY 8(d)'s secondary inputs, into gpurun_out/<round>/variants/ (copy to profiles/<round>/variants/ afterwards):
 #   bash tools/profile_variants.sh r03
-R=${1:-r03}
+R=${1:-r04}
 PART=${2:-all}      # "a": configs[1] variants + configs[3]; "b": configs[4], configs[2], transports; "all"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R/variants
@@ -27,23 +27,20 @@ KR_LANES=4 run configs1_four_sort_lanes --config 1 --steps 10 --warmup 2 --no-cp
 KR_ISECT_KERNEL=1 run configs1_chunk_intersect_kernel --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 KR_ISECT_KERNEL=2 run configs1_pipelined_64bit_heads --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 KR_ISECT_FMT=2 run configs1_32bit_heads_64bit_state --config 1 --steps 10 --warmup 2 --no-cpu-baseline
+KR_ISECT_SPLIT=0 run configs1_no_split_intersection --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 run configs3_per_gpu_load_4x100Mbp --config 3 --steps 10 --warmup 2 --no-cpu-baseline
 run configs3_all_32x100Mbp_one_gpu --config 3 --per-gpu 32 --steps 3 --warmup 1 --no-cpu-baseline
 fi
 if [ "$PART" != a ]; then
-run configs4_2x3Gbp_28_1_2 --config 4 --no-cpu-baseline
+run configs4_2x3Gbp_28_1_2 --config 4
+KR_LANES=1 run configs4_one_lane --config 4 --no-cpu-baseline
+KR_SLICE_ROUTE=0 run configs4_round3_slice_route --config 4 --no-cpu-baseline
 run configs2_8x500Mbp_32_60_32 --config 2
 run configs2_8x500Mbp_32_60_32_mu0.001 --config 2 --mu 0.001 --records 24 --snp-every 20000 --no-cpu-baseline
 run rccl_world1_selftest --config 1 --steps 5 --warmup 2 --no-cpu-baseline --force-comm
 for N in 2 4; do
-  echo "== N=$N ranks sharing the GPU (file transport rehearsal)"
-  rm -rf /tmp/krisp_reh_$N; mkdir -p /tmp/krisp_reh_$N
-  pids=""
-  for r in $(seq 0 $((N-1))); do
-    RANK=$r LOCAL_RANK=$r WORLD_SIZE=$N KRISP_COMM_FILE=/tmp/krisp_reh_$N/c timeout -k 10 600 python3 bench.py --gpus $N --steps 5 --warmup 1 --transport dir --length 10000000 --no-cpu-baseline > "$OUT/rehearsal_n${N}_rank$r.json" 2> "$OUT/rehearsal_n${N}_rank$r.err" &
-    pids="$pids $!"
-  done
-  for p in $pids; do wait $p || echo "rank failed"; done
-  tail -c 600 "$OUT/rehearsal_n${N}_rank0.json" | head -c 600; echo
+  # (no launcher: bench.py starts its own N ranks; they share this box's GPU over the file transport -- the N > 1 flow of
+  # the library, not a scaling measurement)
+  run selflaunch_n${N}_file_transport --gpus $N --transport dir --steps 5 --warmup 1 --no-cpu-baseline
 done
 fi
