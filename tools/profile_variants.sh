@@ -3,7 +3,7 @@
 # for SURVEY 8(d)'s secondary inputs, into gpurun_out/<round>/variants/ (copy to profiles/<round>/variants/ afterwards):
 #   bash tools/profile_variants.sh r03
 R=${1:-r04}
-PART=${2:-all}      # "a": configs[1] variants + configs[3]; "b": configs[4], configs[2], transports; "all"
+PART=${2:-all}      # "a": configs[1] variants + configs[3]; "b1": configs[4]; "b2": configs[2], transports; "b": both; "all"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R/variants
 mkdir -p "$OUT"
@@ -17,7 +17,7 @@ except Exception as e:
     print("   no line:", e)
 PY
 }
-if [ "$PART" != b ]; then
+if [ "$PART" = a ] || [ "$PART" = all ]; then
 run configs1_4x50Mbp --config 1 --steps 10 --warmup 2
 run configs1_independent --config 1 --steps 10 --warmup 2 --no-cpu-baseline --independent
 run configs1_masked --config 1 --steps 10 --warmup 2 --no-cpu-baseline --masked
@@ -27,14 +27,16 @@ KR_LANES=4 run configs1_four_sort_lanes --config 1 --steps 10 --warmup 2 --no-cp
 KR_ISECT_KERNEL=1 run configs1_chunk_intersect_kernel --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 KR_ISECT_KERNEL=2 run configs1_pipelined_64bit_heads --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 KR_ISECT_FMT=2 run configs1_32bit_heads_64bit_state --config 1 --steps 10 --warmup 2 --no-cpu-baseline
-KR_ISECT_SPLIT=0 run configs1_no_split_intersection --config 1 --steps 10 --warmup 2 --no-cpu-baseline
+KR_ISECT_SPLIT=1 run configs1_late_genomes_probe --config 1 --steps 10 --warmup 2 --no-cpu-baseline
 run configs3_per_gpu_load_4x100Mbp --config 3 --steps 10 --warmup 2 --no-cpu-baseline
 run configs3_all_32x100Mbp_one_gpu --config 3 --per-gpu 32 --steps 3 --warmup 1 --no-cpu-baseline
 fi
-if [ "$PART" != a ]; then
+if [ "$PART" = b ] || [ "$PART" = b1 ] || [ "$PART" = all ]; then
 run configs4_2x3Gbp_28_1_2 --config 4
 KR_LANES=1 run configs4_one_lane --config 4 --no-cpu-baseline
 KR_SLICE_ROUTE=0 run configs4_round3_slice_route --config 4 --no-cpu-baseline
+fi
+if [ "$PART" = b ] || [ "$PART" = b2 ] || [ "$PART" = all ]; then
 run configs2_8x500Mbp_32_60_32 --config 2
 run configs2_8x500Mbp_32_60_32_mu0.001 --config 2 --mu 0.001 --records 24 --snp-every 20000 --no-cpu-baseline
 run rccl_world1_selftest --config 1 --steps 5 --warmup 2 --no-cpu-baseline --force-comm
