@@ -861,6 +861,7 @@ def test_late_genomes_probe_the_candidates_of_the_early_ones(N, K, lanes, n, per
         monkeypatch.setenv("KR_ISECT_SPLIT", split)
         with N.Engine() as e:
             e.set_option(N.OPT_LANES, lanes)
+            e.set_option(N.OPT_SLICE_BASES, 0)          # (the probe is for one sort unit: pinned against KR_SLICE_BASES in the environment)
             e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
             for i, (_, _, t) in enumerate(fam):
                 e.upload(i, t)
