@@ -127,7 +127,8 @@ class kstream:
             different shifts of the same direction, which one key layout does not have;
           * unsorted streams (no --sort) of several k, or of inputs that hold characters beyond ACGTN (their k-mers
             would have to be placed by position, not by value), or with --expand-iupac / kept lower case;
-          * k > 32 outside the krisp_fasta combination, flanks > 64, k > 256."""
+          * k > 32 outside the krisp_fasta combination, flanks > 64, k > 256;
+          * a custom column order on an input large enough to need key-space slices (> 2^28 bases: decided at run time)."""
         self.plan_reason = None
         if self.kmers is None or len(self.kmers) < 1:
             return self._no_plan("no k given: the sequences pass through as they are")
@@ -276,6 +277,11 @@ class kstream:
             # (lower case kept: the device takes the windows without any, as under omitsoft; the others are `special`)
             eng.set_params(L, D, R, omit_soft=self.omitsoft or plan["keepcase"], max_bases=len(bases))
             if plan["layout"] == "custom":
+                if eng.debug_info()["nslices"] > 1:
+                    # (a genome of more than 2^28 bases -- or KR_SLICE_BASES in the environment --: the slice digits are the
+                    # first bases of `left`, which a custom layout moves away from the top of the key)
+                    self.plan_reason = "a custom column order on an input that needs key-space slices"
+                    return None
                 eng.set_field_order(fields + [0] * (3 - len(fields)), order + list(range(len(fields), 3)))
             if plan["strands"]:
                 eng.set_strands(plan["strands"])
