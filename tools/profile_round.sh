@@ -28,6 +28,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -- python3
 cd "$ROOT"
 find "$OUT/stats1" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_one_lane.csv"
 find "$OUT/stats1" -type f ! -name "*kernel_stats.csv" -delete
+# one step as a timeline (kernel trace of the plain three-lane command)
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-stage-timers > "$OUT/trace.log" 2>&1
+cd "$ROOT"
+T=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
+python3 tools/step_timeline.py "$T" > "$OUT/step_timeline_3lanes.txt" 2>> "$OUT/bench.err" || echo "no timeline"
+rm -rf "$OUT/trace"
 F=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 python3 profiles/make_traffic.py "$F" "$W" "$OUT/traffic.json" "$R"
