@@ -391,10 +391,11 @@ def _check_intersect(N, K, texts, flags, L, D, R, env=None, kern=0, fmt=0):
 
 @pytest.mark.parametrize("length,threads,mlog", [(500_000, 320, 0), (600_000, 384, 0), (700_000, 448, 0), (800_000, 512, 0),
                                                  (450_000, 512, 1), (3_000, None, None)])
-def test_pipelined_intersect_item_shapes(N, K, length, threads, mlog):
+def test_pipelined_intersect_item_shapes(N, K, length, threads, mlog, monkeypatch):
     """k_intersect3 at every workgroup size the host picks (items of 4 T slots sized from the bucket
     statistics: 256 .. 512 threads, one or several buckets per item), anchor = the shortest genome"""
     from krisp_amd import synth
+    monkeypatch.delenv("KR_SLICE_BASES", raising=False)       # (the shapes below are those of ONE sort unit)
     fam = synth.family(length % 97, 2, 1, length, records=3, mu=0.01, snp_every=1500)
     texts = [t for _, _, t in fam]
     texts[1] = texts[1][: len(texts[1]) - 37]            # the anchor (fewest keys) is not genome 0
