@@ -143,7 +143,7 @@ class WindowGroups:
         self.genome = np.ascontiguousarray(genome, dtype=np.uint32)
         self.labels, self.L, self.D, self.R, self.rna = list(labels), L, D, R, bool(rna)
         self._groups = None
-        self._n = int(len(np.unique(self.cand)))
+        self._n = None
 
     def groups(self):
         if self._groups is None:
@@ -155,6 +155,8 @@ class WindowGroups:
         return self._groups
 
     def __len__(self):
+        if self._n is None:             # (the number of distinct group numbers; the renderer reports it as well)
+            self._n = int(len(np.unique(self.cand)))
         return self._n
 
     def __iter__(self):
@@ -173,7 +175,10 @@ class WindowGroups:
                                                                 dtype=np.uint8)
         out = _native.render_windows(self.rows, self.cand, self.genome, label_of, distinct, label_in, self.L, self.D,
                                      self.R, dot, self.rna)
-        return None if out is None else (out[0], out[1])
+        if out is None:
+            return None
+        self._n = out[2]
+        return out[0], out[1]
 
 
 def groups_from_windows(rows, genome, labels, L, D, R):

@@ -4,6 +4,7 @@
 // cannot run sanitizers on this pool).  Every output buffer is allocated at exactly the size
 // the C ABI documents, so an overrun of one byte is an ASan report.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>

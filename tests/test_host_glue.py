@@ -782,10 +782,16 @@ def test_window_renderer_equals_the_general_path():
                 for g in rng.choice(nl, size=int(rng.integers(1, nl + 1)), replace=False):
                     for _rep in range(int(rng.integers(1, 3))):
                         rows.append(np.concatenate([fl[:L], d, fl[L:]]))
-                        cand.append(gi | (0x80000000 if gi % 3 == 0 else 0))
+                        # (odd rounds: KR_WIDE_HITS order -- a group and its mirror, bit 31, share a region of ascending
+                        # number and interleave inside it; even rounds: any order at all)
+                        cand.append((gi // 2) | ((gi % 2) << 31) if it % 2 else gi | (0x80000000 if gi % 3 == 0 else 0))
                         gen.append(int(g))
         rows = np.frombuffer(b"ACGT", dtype=np.uint8)[np.array(rows)]
-        perm = rng.permutation(len(rows))
+        if it % 2:
+            region = np.array(cand, dtype=np.uint32) & np.uint32(0x7FFFFFFF)
+            perm = np.lexsort((rng.random(len(rows)), region))
+        else:
+            perm = rng.permutation(len(rows))
         rows, cand, gen = rows[perm], np.array(cand, dtype=np.uint32)[perm], np.array(gen, dtype=np.uint32)[perm]
         ingroup = None if it % 3 == 0 else frozenset(labels[:max(1, nl // 2)])
         rna = it % 7 == 3
