@@ -43,7 +43,7 @@ t5 = time.time()
 csv, align = wg.render_text(ingroup, False)
 t6 = time.time()
 print(f"{len(wg):,} groups, {len(rows):,} windows: hits to the host {t3 - t2:.3f} s, windows cut on the device and copied "
-      f"({rows.nbytes / 1e9:.2f} GB) {t4 - t3:.3f} s, group count {t5 - t4:.3f} s, render in the library {t6 - t5:.3f} s "
+      f"({rows.nbytes / 1e9:.2f} GB) {t4 - t3:.3f} s, render in the library (incl. the texts as Python strings) {t6 - t5:.3f} s "
       f"-> CSV {len(csv) / 1e6:.1f} MB, alignment {len(align) / 1e6:.1f} MB; total {t6 - t2:.3f} s")
 # the general path on the first 20000 windows' groups (whole groups): the same text
 cut = 20000
