@@ -103,6 +103,47 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint4* __restrict__ src,
     }
 }
 
+// ---- round 4: what would PACKED 5-byte keys cost / give?  (at k = 28 and fan-out 2^16 the sorted key of a fine bucket
+// has 40 significant bits: VERDICT r3 item 10.)  One array of 5-byte elements, runs of 64 keys = 320 bytes on ANY byte
+// boundary, a key stored as an unaligned dword + a byte; the reader loads 8 unaligned bytes per key.
+typedef u32 __attribute__((aligned(1))) u32u;
+typedef u64 __attribute__((aligned(1))) u64u;
+template <int NOREAD>
+__global__ __launch_bounds__(1024) void k_scatter5(const uint4* __restrict__ src, unsigned char* __restrict__ dst, u32 ntiles,
+                                                   u64 bucket_bytes, u32 shift) {
+    constexpr u32 TK = 16384, RUNK = 64;            // keys per tile, keys per run (256 runs)
+    for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint4* s = src + (u64)t * (TK / 2);
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = NOREAD ? make_uint4(t, q, threadIdx.x, 7) : s[q * 1024 + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const u32 i = q * 1024 + (threadIdx.x & ~63u), lane = threadIdx.x & 63;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const u32 k8 = 2 * i + h * 64 + lane;
+                const u32 r = k8 / RUNK, o = k8 % RUNK;
+                unsigned char* p = dst + (u64)r * bucket_bytes + (u64)t * (RUNK * 5) + o * 5 + shift;
+                const u64 key = h ? (((u64)v[q].w << 32) | v[q].z) : (((u64)v[q].y << 32) | v[q].x);
+                *(u32u*)p = (u32)key;
+                p[4] = (unsigned char)(key >> 32);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_read5(const unsigned char* __restrict__ src, u32* __restrict__ out, u64 nkeys) {
+    const u64 stride = (u64)gridDim.x * 256;
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 acc = 0;
+    for (; i + 3 * stride < nkeys; i += 4 * stride) {
+        const u64 a = *(const u64u*)(src + 5 * i), b = *(const u64u*)(src + 5 * (i + stride)),
+                  c = *(const u64u*)(src + 5 * (i + 2 * stride)), d = *(const u64u*)(src + 5 * (i + 3 * stride));
+        acc += (a & 0xFFFFFFFFFFull) ^ (b & 0xFFFFFFFFFFull) ^ (c & 0xFFFFFFFFFFull) ^ (d & 0xFFFFFFFFFFull);
+    }
+    if (acc == 0x12345) out[0] = (u32)acc;
+}
+
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <typename F>
@@ -188,6 +229,24 @@ int main() {
             printf("  +%2u B: %4.0f", shift8 * 8, 1.0 * N16 * 16 / t / 1e6);
         }
         printf("  GB/s\n");
+    }
+    // packed 5-byte keys: pass 2's pattern (16384-key tiles, 256 runs of 64 keys) written as 320-byte runs on any byte
+    // boundary against the 512-byte runs of 8-byte keys above; and a streaming read of the packed array
+    {
+        const u32 ntiles = (u32)(2 * N16 / 16384);
+        const u64 bucket_bytes = (u64)ntiles * 320;
+        for (u32 shift : {0u, 1u, 3u, 5u}) {
+            double t = timeit([&] { hipLaunchKernelGGL(k_scatter5<0>, dim3(256), dim3(1024), 0, 0, a, (unsigned char*)b, ntiles, bucket_bytes, shift); }, 5);
+            printf("packed 5-byte keys, runs 320 B, +%u B: %5.1f G keys/s = %4.0f GB/s moved (8-byte form at 512-B runs: see below)\n", shift,
+                   (double)ntiles * 16384 / t / 1e6, (double)ntiles * 16384 * 13 / t / 1e6);
+        }
+        const u64 nk = (u64)ntiles * 16384;
+        for (int grid : {2048, 8192}) {
+            double t = timeit([&] { hipLaunchKernelGGL(k_read5, dim3(grid), dim3(256), 0, 0, (const unsigned char*)b, out, nk); }, 10);
+            printf("packed 5-byte keys, streaming read, grid %d: %5.1f G keys/s = %4.0f GB/s of packed bytes\n", grid, nk / t / 1e6, nk * 5 / t / 1e6);
+        }
+        double t8 = timeit([&] { hipLaunchKernelGGL((k_scatter<32, 1>), dim3(256), dim3(1024), 0, 0, a, b, (u32)(N16 / (256 * 32)), (u64)(N16 / (256 * 32)) * 32, 1u, 0u); }, 5);
+        printf("8-byte keys, runs 512 B, +8 B: %5.1f G keys/s = %4.0f GB/s moved\n", 2.0 * N16 / t8 / 1e6, 2.0 * N16 * 16 / t8 / 1e6);
     }
     run(std::integral_constant<int, 8>{}, 128);
     run(std::integral_constant<int, 16>{}, 256);
