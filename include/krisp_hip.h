@@ -239,17 +239,19 @@ int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines,
                           size_t cap, int64_t* stats);
 
 /* Host-side ingest of one FILE: read -> inflate (.gz: libdeflate when the box
- * has it, else zlib; every member of a multi-member file) -> kr_fasta_to_bases, with the reference
+ * has it, else zlib; every member of a multi-member file, BGZF members side by side on host threads,
+ * one large member cut into chunks that decode side by side -- csrc/h_pgzip.inc; .bz2: libbz2,
+ * streams side by side) -> kr_fasta_to_bases, with the reference
  * reader's semantics for files (kstream.py:458-479: .gz by extension; 510-583).  *bases = a buffer
  * the library owns -- pinned host memory when a GPU is present, so that kr_genome_upload copies
  * from it by DMA -- until kr_host_free.  stats[8] = records, characters outside ACGTNacgtn, is_rna,
  * is_fasta, read us, inflate us, parse us, gzip members | used_libdeflate << 32.  Returns the
- * number of bytes; .bz2 files return KR_ERR_HOST (the host layer inflates them). */
+ * number of bytes; a .bz2 file on a box without libbz2 returns KR_ERR_HOST (the host layer inflates it). */
 int64_t kr_ingest_file(const char* path, uint8_t** bases, int64_t* stats);
 /* The same ingest with the PARSE on the device (the host reads and inflates only):
  *   kr_read_file            the file's text in pinned host memory (free with kr_host_free); stats[8]: [3] = 1 when the
  *                           text wants universal newlines (a plain file), [4] read us, [5] inflate us, [6] copy us,
- *                           [7] gzip members | used_libdeflate << 32.  Returns the number of bytes; .bz2: KR_ERR_HOST.
+ *                           [7] gzip members | used_libdeflate << 32.  Returns the number of bytes (.bz2 without libbz2: KR_ERR_HOST).
  *   kr_genome_upload_text   text -> genome `id`'s upload buffer, parsed on the device (csrc/k_text.inc) with exactly
  *                           kr_fasta_to_bases' result (the tests compare them byte for byte), then as
  *                           kr_genome_upload.  stats[4] = records, characters outside ACGTNacgtn, is_rna, is_fasta.

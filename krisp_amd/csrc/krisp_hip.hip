@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cerrno>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -43,6 +44,7 @@
 #include "h_core.inc"        // context, buffers, parameters, upload, sort, finalize   (opens extern "C")
 #include "h_intersect.inc"   // kr_intersect, candidate lists, kr_collect
 #include "h_wide.inc"        // kr_wide_run
+#include "h_pgzip.inc"       // one gzip member inflated on several threads (host only)
 #include "h_ingest.inc"      // file -> inflate -> parse -> pinned upload buffer (host side)
 #include "h_comm.inc"        // multi-GPU exchange: RCCL (or files, for rehearsal) tree reduction of candidates, gather of records
 #include "h_text.inc"        // FASTA text parser, IUPAC side-channel scan (host only, no HIP)

@@ -3,12 +3,16 @@
 // Built and run by tests/test_host_glue.py::test_text_code_under_address_sanitizer (g++; the GPU
 // cannot run sanitizers on this pool).  Every output buffer is allocated at exactly the size
 // the C ABI documents, so an overrun of one byte is an ASan report.
+#include <zlib.h>
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,6 +22,7 @@
 static thread_local std::string g_last_error;
 extern "C" {
 #include "../../krisp_amd/csrc/h_text.inc"
+#include "../../krisp_amd/csrc/h_pgzip.inc"
 }
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -180,6 +185,49 @@ int main() {
                                   &csv, &nc, &al, &na) != KR_ERR_PARAM) return 12;
         }
     }
-    printf("ASAN_HOST_OK %ld scans %ld renders %ld window renders\n", checks, renders, wrenders);
+    // ---- one gzip member on several threads (h_pgzip.inc): texts of several kinds, every level and strategy, chunks as
+    // small as they go; then the same members damaged -- whatever comes back, nothing may be read or written out of bounds,
+    // and a member that is "done" must be the text
+    long members = 0, refused = 0;
+    for (int it = 0; it < 60; it++) {
+        const size_t n = 200000 + rnd() % 1500000;
+        std::vector<uint8_t> text(n);
+        const int kind = it % 5;
+        for (size_t i = 0; i < n; i++) {
+            if (kind == 0) text[i] = (uint8_t)"ACGT"[rnd() & 3];
+            else if (kind == 1) text[i] = (uint8_t)(i % 71 == 70 ? '\n' : "ACGTN"[rnd() % 5]);
+            else if (kind == 2) text[i] = (uint8_t)rnd();
+            else if (kind == 3) text[i] = (uint8_t)(i > 40000 && (rnd() & 7) ? text[i - 1 - rnd() % 40000] : "ACGT"[rnd() & 3]);
+            else text[i] = (uint8_t)((i / 5000) & 1 ? 'A' : "ACGT"[rnd() & 3]);
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        const int level = it % 10, strategy = (it / 10) % 4 == 3 ? Z_FIXED : ((it / 10) % 4 == 2 ? Z_RLE : Z_DEFAULT_STRATEGY);
+        if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 1 + rnd() % 9, strategy) != Z_OK) return 20;
+        std::vector<uint8_t> gz(deflateBound(&zs, (uLong)n) + 64);
+        zs.next_in = text.data(); zs.avail_in = (uInt)n;
+        zs.next_out = gz.data(); zs.avail_out = (uInt)gz.size();
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return 21;
+        gz.resize(gz.size() - zs.avail_out);
+        deflateEnd(&zs);
+        for (int damage = 0; damage < 4; damage++) {
+            std::vector<uint8_t> blob(gz);                  // (exactly as long as the member: a read behind it is an ASan report)
+            if (damage == 1) blob[blob.size() / 3 + rnd() % (blob.size() / 3)] ^= (uint8_t)(1 + rnd() % 255);
+            if (damage == 2) blob.resize(blob.size() / 2 + rnd() % (blob.size() / 2));
+            if (damage == 3) for (int q = 0; q < 20; q++) blob[20 + rnd() % (blob.size() - 20)] = (uint8_t)rnd();
+            PgzMember m;
+            const int r = pgz_decode_member(blob.data(), blob.size(), 3, 65536, m);
+            if (r == 1) {
+                std::vector<uint8_t> out(m.total);
+                const int e = pgz_emit(m, out.data(), 3);
+                if (e == 1 && (m.total != n || memcmp(out.data(), text.data(), n) != 0)) { printf("another text accepted\n"); return 22; }
+                if (e == 1) members++; else refused++;
+                if (damage == 0 && e != 1) { printf("sound member refused by its checksum\n"); return 23; }
+            } else {
+                refused++;
+            }
+        }
+    }
+    printf("ASAN_HOST_OK %ld scans %ld renders %ld window renders %ld members on threads %ld refused\n", checks, renders, wrenders, members, refused);
     return 0;
 }

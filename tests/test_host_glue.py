@@ -515,7 +515,7 @@ def test_text_code_under_address_sanitizer(tmp_path):
     exe = str(tmp_path / "asan_host")
     src = os.path.join(ROOT, "tests", "native", "asan_host.cpp")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe, src])
+                           "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-lz"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ASAN_HOST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
@@ -753,6 +753,70 @@ def test_library_reads_bz2_and_block_gzip_as_python_does(tmp_path, monkeypatch):
         p.write_bytes(blob)
         with pytest.raises(_native.KrispHipError):
             _native.read_file(str(p))
+
+
+def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
+    """h_pgzip.inc: a large gzip member is cut into chunks, a block start is FOUND in each, the chunks decode side by side
+    (16-bit symbols with markers for what they copy from the unknown 32 KB in front, zlib once no marker is left) and are
+    stitched, checked against CRC-32 and ISIZE -- the text gzip.open gives (kstream.py:458-479), for DNA, repeats, noise,
+    runs and prose at every kind of block (stored, fixed, dynamic), with header fields, small windows, several members and
+    zero padding; chunks as small as they go, so that every file has dozens of joins.  Damaged and cut files are refused."""
+    import struct
+    import zlib
+    from krisp_amd import _native
+    rng = np.random.default_rng(23)
+    monkeypatch.setenv("KRISP_PGZIP_MIN", "0")
+    monkeypatch.setenv("KRISP_PGZIP_CHUNK", "65536")
+    monkeypatch.setenv("KRISP_INGEST_THREADS", "4")
+
+    def dna(n, width=70):
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+        return b">r\n" + b"\n".join(seq[i:i + width].tobytes() for i in range(0, n, width)) + b"\n"
+
+    def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, fields=False, wbits=15, memlevel=8):
+        c = zlib.compressobj(level, zlib.DEFLATED, -wbits, memlevel, strategy)
+        body = c.compress(data) + c.flush()
+        hdr = b"\x1f\x8b\x08" + (b"\x0c" if fields else b"\0") + b"\0\0\0\0\0\xff"
+        if fields:
+            hdr += struct.pack("<H", 5) + b"hello" + b"file.fa\0"
+        return hdr + body + struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF)
+
+    texts = {
+        "dna": dna(1_200_000),
+        "repeats": dna(150_000) * 7,
+        "noise": rng.integers(0, 256, size=500_000, dtype=np.uint8).tobytes(),
+        "runs": b"".join(bytes([65 + int(x)]) * int(n) for x, n in zip(rng.integers(0, 4, 8000), rng.integers(1, 300, 8000))),
+        "prose": (b"the quick brown fox jumps over the lazy dog; " * 40 + b"\x07\xf3") * 600,
+    }
+    cases = []
+    for tn, t in texts.items():
+        for level in (0, 1, 6, 9):
+            cases.append((f"{tn}_l{level}", member(t, level), t))
+        cases.append((f"{tn}_fixed", member(t, 6, zlib.Z_FIXED), t))
+        cases.append((f"{tn}_huffman", member(t, 6, zlib.Z_HUFFMAN_ONLY), t))
+        cases.append((f"{tn}_fields_w9", member(t, 6, fields=True, wbits=9, memlevel=1), t))
+    t = texts["dna"]
+    cases.append(("three", member(t[:400_000]) + member(t[400_000:900_000], 9) + member(t[900_000:], 1) + b"\0" * 5, t))
+    cases.append(("many", b"".join(member(t[i:i + 5000]) for i in range(0, 300_000, 5000)), t[:300_000]))
+    for name, blob, want in cases:
+        p = tmp_path / (name + ".fa.gz")
+        p.write_bytes(blob)
+        for on in ("1", "0"):
+            monkeypatch.setenv("KRISP_PGZIP", on)
+            arr, universal, timings = _native.read_file(str(p))
+            assert arr.tobytes() == want, (name, on)
+        assert timings["members"] == {"three": 3, "many": 60}.get(name, 1)
+    monkeypatch.setenv("KRISP_PGZIP", "1")
+    blob = bytearray(member(t, 6))
+    for at in (len(blob) // 2, len(blob) - 3, len(blob) - 7, 30):
+        b2 = bytearray(blob)
+        b2[at] ^= 0x5A
+        (tmp_path / "bad.fa.gz").write_bytes(bytes(b2))
+        with pytest.raises(_native.KrispHipError):
+            _native.read_file(str(tmp_path / "bad.fa.gz"))
+    (tmp_path / "cut.fa.gz").write_bytes(bytes(blob[:len(blob) * 2 // 3]))
+    with pytest.raises(_native.KrispHipError):
+        _native.read_file(str(tmp_path / "cut.fa.gz"))
 
 
 def test_window_renderer_equals_the_general_path():
