@@ -801,12 +801,14 @@ def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
     for name, blob, want in cases:
         p = tmp_path / (name + ".fa.gz")
         p.write_bytes(blob)
-        for on in ("1", "0"):
+        for on, zl in (("1", "0"), ("1", "1"), ("0", "0")):      # our byte decoder behind the markers / zlib there / one thread
             monkeypatch.setenv("KRISP_PGZIP", on)
+            monkeypatch.setenv("KRISP_PGZIP_ZLIB", zl)
             arr, universal, timings = _native.read_file(str(p))
-            assert arr.tobytes() == want, (name, on)
+            assert arr.tobytes() == want, (name, on, zl)
         assert timings["members"] == {"three": 3, "many": 60}.get(name, 1)
     monkeypatch.setenv("KRISP_PGZIP", "1")
+    monkeypatch.setenv("KRISP_PGZIP_ZLIB", "0")
     blob = bytearray(member(t, 6))
     for at in (len(blob) // 2, len(blob) - 3, len(blob) - 7, 30):
         b2 = bytearray(blob)
