@@ -241,7 +241,7 @@ int64_t kr_fasta_to_bases(const uint8_t* text, size_t n, int universal_newlines,
 /* Host-side ingest of one FILE: read -> inflate (.gz: libdeflate when the box
  * has it, else zlib; every member of a multi-member file, BGZF members side by side on host threads,
  * one large member cut into chunks that decode side by side -- csrc/h_pgzip.inc; .bz2: libbz2,
- * streams side by side) -> kr_fasta_to_bases, with the reference
+ * block by block on host threads) -> kr_fasta_to_bases, with the reference
  * reader's semantics for files (kstream.py:458-479: .gz by extension; 510-583).  *bases = a buffer
  * the library owns -- pinned host memory when a GPU is present, so that kr_genome_upload copies
  * from it by DMA -- until kr_host_free.  stats[8] = records, characters outside ACGTNacgtn, is_rna,

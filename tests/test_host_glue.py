@@ -755,6 +755,43 @@ def test_library_reads_bz2_and_block_gzip_as_python_does(tmp_path, monkeypatch):
             _native.read_file(str(p))
 
 
+def test_bz2_blocks_decode_side_by_side(tmp_path, monkeypatch):
+    """inflate_bz2_blocks (csrc/h_ingest.inc): the blocks of a bzip2 stream are found by their 48-bit mark on any bit, the
+    file's structure is walked (stream headers, blocks back to back, end marks, combined checksums), every block is wrapped
+    into a stream of its own and the blocks decode side by side -- the text bz2.open gives (kstream.py:458-479), for one
+    stream of many blocks at several block sizes, several streams, an empty stream in front, long runs (one block: the
+    sequential route); damaged and cut files are refused."""
+    import bz2
+    from krisp_amd import _native
+    rng = np.random.default_rng(29)
+    monkeypatch.setenv("KRISP_INGEST_THREADS", "4")
+    seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=2_500_000)
+    t = b">r\n" + b"\n".join(seq[i:i + 70].tobytes() for i in range(0, len(seq), 70)) + b"\n"
+    runs = b"".join(bytes([65 + int(x)]) * int(k) for x, k in zip(rng.integers(0, 4, 9000), rng.integers(1, 600, 9000)))
+    cases = [("l9", bz2.compress(t, 9), t, 1), ("l1", bz2.compress(t, 1), t, 1), ("l4", bz2.compress(t, 4), t, 1),
+             ("three", bz2.compress(t[:400_000], 9) + bz2.compress(t[400_000:1_500_000], 2) + bz2.compress(t[1_500_000:], 9) + b"\0" * 9, t, 3),
+             ("empty_first", bz2.compress(b"") + bz2.compress(t[:300_000], 1), t[:300_000], 2),
+             ("runs", bz2.compress(runs, 9), runs, 1)]
+    for name, blob, want, nstreams in cases:
+        p = tmp_path / (name + ".fa.bz2")
+        p.write_bytes(blob)
+        for on in ("1", "0"):
+            monkeypatch.setenv("KRISP_PBZ2", on)
+            arr, universal, timings = _native.read_file(str(p))
+            assert arr.tobytes() == want and timings["members"] == nstreams, (name, on)
+    monkeypatch.setenv("KRISP_PBZ2", "1")
+    blob = bytearray(cases[1][1])
+    for at in (len(blob) // 2, len(blob) - 2, 3, 12):
+        b2 = bytearray(blob)
+        b2[at] ^= 0x10
+        (tmp_path / "bad.fa.bz2").write_bytes(bytes(b2))
+        with pytest.raises(_native.KrispHipError):
+            _native.read_file(str(tmp_path / "bad.fa.bz2"))
+    (tmp_path / "cut.fa.bz2").write_bytes(bytes(blob[:len(blob) // 2]))
+    with pytest.raises(_native.KrispHipError):
+        _native.read_file(str(tmp_path / "cut.fa.bz2"))
+
+
 def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
     """h_pgzip.inc: a large gzip member is cut into chunks, a block start is FOUND in each, the chunks decode side by side
     (16-bit symbols with markers for what they copy from the unknown 32 KB in front, zlib once no marker is left) and are
