@@ -38,6 +38,10 @@ rm -rf "$OUT/trace"
 F=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 python3 profiles/make_traffic.py "$F" "$W" "$OUT/traffic.json" "$R"
+# the bench line once more, now with the PMC file of this very build beside it (roofline.traffic, roofline.step)
+cp "$OUT/traffic.json" "$ROOT/profiles/traffic.json"
+python3 bench.py > "$OUT/bench.json" 2>> "$OUT/bench.err"
+tail -1 "$OUT/bench.json" | head -c 600; echo
 # the raw per-dispatch csv files are large: keep the summaries only
 rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
 find "$OUT/stats" -type f ! -name "*kernel_stats.csv" -delete
