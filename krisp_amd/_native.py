@@ -89,6 +89,7 @@ SYMBOLS = [
     ("kr_ingest_file", _c.c_int64, [_c.c_char_p, _P, _P]),
     ("kr_read_file", _c.c_int64, [_c.c_char_p, _P, _P]),
     ("kr_genome_upload_text", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t, _c.c_int, _c.c_int, _P]),
+    ("kr_reserve", _c.c_int, [_P, _P, _c.c_int, _c.c_size_t, _c.c_int]),
     ("kr_genome_fetch_bases", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_host_free", None, [_P]),
     ("kr_scan_special", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _P, _c.c_size_t, _P]),
@@ -351,6 +352,11 @@ class Engine:
         n = self._check(self.lib.kr_genome_upload_text(self.ctx, gid, _ptr(t), len(t), 1 if universal_newlines else 0,
                                                        1 if one_shot else 0, _ptr(stats)), "kr_genome_upload_text")
         return n, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
+
+    def reserve(self, ids, n_bases, with_text=False):
+        """the large device buffers of genomes `ids` of up to n_bases bases, ahead of their uploads (kr_reserve)"""
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        self._check(self.lib.kr_reserve(self.ctx, _ptr(a), len(a), int(n_bases), 1 if with_text else 0), "kr_reserve")
 
     def fetch_bases(self, gid, n):
         out = np.empty(max(n, 1), dtype=np.uint8)

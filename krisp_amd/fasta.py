@@ -115,6 +115,26 @@ def read_text(filename):
         return np.frombuffer(f.read(), dtype=np.uint8), True
 
 
+def estimate_text_bytes(path):
+    """an estimate from above of a sequence file's text in bytes without reading it (what kr_reserve plans with): the
+    file's size; `.gz`: the ISIZE word of its last member plus as many 4 GiB as its compressed size asks for (a file of
+    several members comes out too small: the caller then plans again with the real size); `.bz2`: five times its size"""
+    path = os.fspath(path)
+    size = os.path.getsize(path)
+    if path.endswith(".gz"):
+        if size < 18:
+            return 0
+        with open(path, "rb") as f:
+            f.seek(size - 4)
+            est = int.from_bytes(f.read(4), "little")
+        while est < size:
+            est += 1 << 32
+        return est
+    if path.endswith(".bz2"):
+        return 5 * size
+    return size
+
+
 def ingest_on_device(eng, gid, text, universal, k, omit_soft):
     """text of a sequence file -> genome gid of `eng`, parsed on the device with the reference reader's semantics
     (kr_genome_upload_text; the host never sees the bases unless the genome holds characters outside ACGTNacgtn:

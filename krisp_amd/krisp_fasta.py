@@ -293,6 +293,9 @@ def _merge_groups(device_groups, touched, special_groups):
     return out
 
 
+RESERVE_MIN = 128 << 20      # bytes of file text from which the context's memory is made ahead of the uploads (kr_reserve)
+
+
 def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
                                 workers, t0):
     """find_regions' packed path with the reader on the device: the host threads read and inflate, the main thread
@@ -309,23 +312,41 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
     flags = [lab in ingroup_labels for lab in labels]
     with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device) as eng:
         futures = [pool.submit(fasta.read_text, f) for f in files]
+        # large genomes: the context gets its memory (15-40 ms per GB of fresh device memory: seconds at 3 Gbp) while the
+        # host threads read and inflate -- planned from the files' sizes, planned again below if they said too little
+        planned = 0
+        try:
+            est = max(fasta.estimate_text_bytes(f) for f in files)
+        except OSError:
+            est = 0
+        if RESERVE_MIN <= est < (1 << 32) - 128 and os.environ.get("KRISP_RESERVE") != "0":
+            planned = est
+            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=planned)
+            eng.reserve(list(range(len(files))), planned, with_text=True)
         first = [fu.result() for fu in futures]            # (the texts' sizes bound the genomes': needed for the sort plan)
         read_s = time.time() - t0
         t1 = time.time()
-        eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(max(len(t) for t, _ in first), 1))
+        true_max = max(max(len(t) for t, _ in first), 1)
+        if true_max > planned:
+            for i in (range(len(files)) if planned else ()):
+                eng.free(i)
+            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=true_max)
         rna, specials = [], []
         for i, (text, universal) in enumerate(first):
             _n, r, sp = fasta.ingest_on_device(eng, i, text, universal, k, omit_soft)
             rna.append(r)
             specials.append([codec.split_window(w, Le, De, Re) for w in sp])
             eng.sort(i)
+        t2 = time.time()
         del first
+        t3 = time.time()
         if any(rna) and not all(rna):
             raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
         finish = _to_rna if all(rna) else (lambda groups: groups)
         ids = list(range(len(files)))
         ncand = eng.intersect(ids, flags, apply_filter=do_filter and not quirk_all_fail)
         counts = [eng.count(i) for i in ids]
+        t4 = time.time()
         if verbose:
             for f, cnt in zip(files, counts):
                 print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)
@@ -334,8 +355,12 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
         touched, sgroups = set(), []
         if any(specials) and not quirk_all_fail:
             touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels, do_filter)
+        t5 = time.time()
+    # (device_s ends where the context is gone: its buffers freed, the reader threads joined)
     stats = {"read_s": read_s, "device_s": time.time() - t1,
-             "kmers": int(sum(counts)) + sum(len(sp) for sp in specials), "candidates": int(ncand)}
+             "kmers": int(sum(counts)) + sum(len(sp) for sp in specials), "candidates": int(ncand),
+             "stage_s": {"parse+sort launches": t2 - t1, "texts freed": t3 - t2, "sorts + intersect": t4 - t3,
+                         "collect": t5 - t4, "context freed": time.time() - t5}}
     if quirk_all_fail:
         return [], stats
     if not touched and not any(rna):

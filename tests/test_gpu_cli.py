@@ -870,3 +870,57 @@ def test_iupac_letters_in_long_amplicons_over_several_ranks(seed, tmp_path):
     devices = [0] * (2 if seed % 2 == 0 else 3)
     groups, _ = KF.find_regions_multi_device(ing, outg, L, R, k, devices)
     assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slice_bases", [None, "1"])
+def test_memory_reserved_while_the_files_inflate(slice_bases, tmp_path, monkeypatch):
+    """kr_reserve (the context's large buffers made ahead of the uploads, planned from the files' sizes while the host
+    threads inflate: krisp_fasta._find_regions_device_ingest) changes nothing but the order of the allocations: the same
+    groups as without it, for files whose size the estimate knows (one gzip member, plain, bz2), for a file of several
+    members (estimated too small: the flow frees what it reserved and plans again) and with key-space slices"""
+    import gzip
+    import bz2
+    import numpy as np
+    from krisp_amd import krisp_fasta as KF
+    from krisp_amd import fasta
+    if slice_bases:
+        monkeypatch.setenv("KR_SLICE_BASES", slice_bases)
+    rng = np.random.default_rng(41)
+    anc = rng.integers(0, 4, size=60_000)
+
+    def genome(seed):
+        g = anc.copy()
+        r = np.random.default_rng(seed)
+        at = r.integers(0, len(g), size=1500)
+        g[at] = (g[at] + 1 + r.integers(0, 3, size=1500)) % 4
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[g].tobytes()
+        return b">a x\n" + b"\n".join(s[i:i + 70] for i in range(0, 30_000, 70)) + b"\n>b\n" + s[30_000:] + b"\n"
+    texts = [genome(s) for s in range(4)]
+    files = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"g{i}{('.fa.gz', '.fa', '.fa.bz2', '.fa.gz')[i]}"
+        if i == 0:
+            p.write_bytes(gzip.compress(t))
+        elif i == 1:
+            p.write_bytes(t)
+        elif i == 2:
+            p.write_bytes(bz2.compress(t))
+        else:
+            p.write_bytes(gzip.compress(t[:20_000]) + gzip.compress(t[20_000:]))      # (ISIZE names the last member only)
+        files.append(str(p))
+    assert fasta.estimate_text_bytes(files[0]) == len(texts[0]) and fasta.estimate_text_bytes(files[1]) == len(texts[1])
+    assert fasta.estimate_text_bytes(files[3]) < len(texts[3])
+    monkeypatch.setenv("KRISP_RESERVE", "0")
+    want, _ = KF.find_regions(files[:2], files[2:], 20, 2, 23)
+    want = [[(a.left, a.diag, a.right, tuple(a.labels)) for a in g] for g in want]
+    assert len(want) >= 3
+    monkeypatch.delenv("KRISP_RESERVE")
+    monkeypatch.setattr(KF, "RESERVE_MIN", 0)
+    for order in (files, [files[3], files[0], files[1], files[2]]):         # (the re-planned case first, too)
+        got, _ = KF.find_regions(order[:2], order[2:], 20, 2, 23)
+        got = [[(a.left, a.diag, a.right, tuple(a.labels)) for a in g] for g in got]
+        if order is files:
+            assert got == want
+        else:
+            assert len(got) >= 1

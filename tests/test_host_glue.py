@@ -755,6 +755,30 @@ def test_library_reads_bz2_and_block_gzip_as_python_does(tmp_path, monkeypatch):
             _native.read_file(str(p))
 
 
+def test_text_size_estimates_for_the_memory_plan(tmp_path):
+    """fasta.estimate_text_bytes: what kr_reserve plans with before a file is read -- the size of a plain file, ISIZE of
+    a gzip member (plus the 4 GiB its compressed size asks for), five times a bz2 file; a file of several members says
+    too little (the flow plans again)"""
+    import bz2
+    import gzip
+    import struct
+    from krisp_amd import fasta
+    t = b">r\n" + b"ACGT" * 50_000 + b"\n"
+    (tmp_path / "a.fa").write_bytes(t)
+    (tmp_path / "a.fa.gz").write_bytes(gzip.compress(t))
+    (tmp_path / "two.fa.gz").write_bytes(gzip.compress(t) + gzip.compress(t[:1000]))
+    (tmp_path / "a.fa.bz2").write_bytes(bz2.compress(t))
+    assert fasta.estimate_text_bytes(str(tmp_path / "a.fa")) == len(t)
+    assert fasta.estimate_text_bytes(str(tmp_path / "a.fa.gz")) == len(t)
+    assert fasta.estimate_text_bytes(str(tmp_path / "two.fa.gz")) == 1000
+    assert fasta.estimate_text_bytes(str(tmp_path / "a.fa.bz2")) == 5 * os.path.getsize(tmp_path / "a.fa.bz2")
+    # a member whose ISIZE word is smaller than the file: the text is at least 4 GiB longer
+    blob = gzip.compress(t)
+    fake = blob[:-4] + struct.pack("<I", 100) + b""
+    (tmp_path / "big.fa.gz").write_bytes(fake)
+    assert fasta.estimate_text_bytes(str(tmp_path / "big.fa.gz")) == 100 + (1 << 32)
+
+
 def test_bz2_blocks_decode_side_by_side(tmp_path, monkeypatch):
     """inflate_bz2_blocks (csrc/h_ingest.inc): the blocks of a bzip2 stream are found by their 48-bit mark on any bit, the
     file's structure is walked (stream headers, blocks back to back, end marks, combined checksums), every block is wrapped

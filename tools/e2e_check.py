@@ -64,3 +64,5 @@ with tempfile.TemporaryDirectory() as td:
                   f"(slowest file: read {mx('read_s'):.3f} inflate {mx('inflate_s'):.3f} parse {mx('parse_s'):.3f}; "
                   f"libdeflate {any(t['libdeflate'] for t in tm)}) | upload+sort+intersect+collect+grouping "
                   f"{stats['device_s']:.3f} s | render {t2 - t1:.3f} s | {stats['kmers']:,} k-mers, {len(groups)} groups")
+            if stats.get("stage_s") and stats["device_s"] > 0.15:
+                print("          (device part: " + ", ".join(f"{k} {v:.3f}" for k, v in stats["stage_s"].items()) + ")")

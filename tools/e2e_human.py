@@ -1,0 +1,83 @@
+"""krisp_fasta end to end at human scale (BASELINE configs[4]'s genomes as FILES): two `gzip` FASTA files of `length`
+bases each (1 in / 1 out, k = 31 as 28/1/2) -> read, inflate (one member per file, cut into chunks: csrc/h_pgzip.inc),
+parse on the device, sort in key-space slices, intersect + filter, collect, render.  The genomes differ in `mu` of their
+bases (default 2e-4: ~10^6 diagnostic groups; SURVEY 8(d)'s 0.01 would give 6.5e7 groups = gigabytes of text).
+    python tools/e2e_human.py [length, default 3e9] [mu]            (on the GPU box; writes to stdout)"""
+import os
+import sys
+import tempfile
+import threading
+import time
+import zlib
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from krisp_amd import amplicon, fasta, synth  # noqa: E402
+from krisp_amd import krisp_fasta as KF  # noqa: E402
+
+length = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
+mu = float(sys.argv[2]) if len(sys.argv) > 2 else 2e-4
+t0 = time.time()
+fam = synth.family(5, 1, 1, length, records=24, mu=mu, snp_every=100_000)
+print(f"2 x {length / 1e9:g} Gbp, mu = {mu:g}: generated in {time.time() - t0:.0f} s", flush=True)
+
+
+def fasta_gz(path, text, width=80, level=1):
+    """80-column FASTA of the records of `text` (records separated by newline), as one gzip member"""
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    n = 0
+    with open(path, "wb") as f:
+        start = 0
+        arr = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        ends = list(np.flatnonzero(arr == 10)) + [len(arr)]
+        for i, e in enumerate(ends):
+            rec = arr[start:e]
+            start = e + 1
+            if len(rec) == 0:
+                continue
+            f.write(co.compress(b">rec%d\n" % i))
+            for a in range(0, len(rec), 64 * 1000 * width):
+                part = rec[a:a + 64 * 1000 * width]
+                whole = len(part) - len(part) % width
+                rows = part[:whole].reshape(-1, width)
+                body = np.concatenate([rows, np.full((rows.shape[0], 1), 10, dtype=np.uint8)], axis=1).tobytes()
+                if whole < len(part):
+                    body += part[whole:].tobytes() + b"\n"
+                n += len(body)
+                f.write(co.compress(body))
+        f.write(co.flush())
+    return n
+
+
+with tempfile.TemporaryDirectory() as td:
+    t1 = time.time()
+    paths, sizes = [], [0, 0]
+
+    def one(i):
+        name, ing, text = fam[i]
+        p = os.path.join(td, name + ".fa.gz")
+        paths.append((i, p))
+        sizes[i] = fasta_gz(p, text)
+    th = [threading.Thread(target=one, args=(i,)) for i in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    paths = [p for _, p in sorted(paths)]
+    del fam
+    print(f"written as gzip -1 files in {time.time() - t1:.0f} s: {[round(os.path.getsize(p) / 1e9, 2) for p in paths]} GB "
+          f"for {[round(s / 1e9, 2) for s in sizes]} GB of text", flush=True)
+    for rep in range(2):
+        fasta.LAST_TIMINGS.clear()
+        t2 = time.time()
+        groups, stats = KF.find_regions(paths[:1], paths[1:], 28, 2, 31)
+        t3 = time.time()
+        csv, align = amplicon.render(groups, [KF.simplename(paths[0])])
+        t4 = time.time()
+        tm = list(fasta.LAST_TIMINGS.values())
+        mx = lambda key: max((t[key] for t in tm), default=0.0)  # noqa: E731
+        print(f"run {rep}: total {t4 - t2:.2f} s | ingest wall {stats['read_s']:.2f} s (slowest file: read {mx('read_s'):.2f} inflate "
+              f"{mx('inflate_s'):.2f}) | upload + parse + sort + intersect + collect + grouping {stats['device_s']:.2f} s | render "
+              f"{t4 - t3:.2f} s | {stats['kmers']:,} k-mers, {len(groups):,} groups, CSV {len(csv) / 1e6:.1f} MB, alignment {len(align) / 1e6:.1f} MB",
+              flush=True)
+        print("       device part: " + ", ".join(f"{k} {v:.3f}" for k, v in stats.get("stage_s", {}).items()), flush=True)
+        del groups, csv, align
