@@ -1,7 +1,7 @@
 """One gzip member on several host threads (csrc/h_pgzip.inc; SURVEY 8(f) rank 1, kstream.py:458-479): how long the library
 takes to turn a `gzip genome.fa` file into text, with the member cut into chunks against one thread, for one large genome
 and for the four 50 Mbp files of configs[1] read side by side as the command line reads them.
-    python tools/pgzip_check.py [Mbp of the large genome, default 400]          (on the GPU box; writes to stdout)"""
+    python tools/pgzip_check.py [Mbp of the large genome, default 400] [gzip level, default 6]     (on the GPU box; writes to stdout)"""
 import gzip
 import os
 import sys
@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from krisp_amd import _native  # noqa: E402
 
 mbp = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 tmp = os.environ.get("TMPDIR", "/tmp")
 rng = np.random.default_rng(31)
 
@@ -48,8 +49,8 @@ t0 = time.time()
 text = fasta(mbp * 1_000_000)
 big = os.path.join(tmp, "pgz_big.fa.gz")
 with open(big, "wb") as f:
-    f.write(gzip.compress(text, compresslevel=6))
-print(f"{mbp} Mbp genome: {len(text) / 1e6:.0f} MB of text, {os.path.getsize(big) / 1e6:.0f} MB as .gz (level 6), written in {time.time() - t0:.0f} s", flush=True)
+    f.write(gzip.compress(text, compresslevel=level))
+print(f"{mbp} Mbp genome: {len(text) / 1e6:.0f} MB of text, {os.path.getsize(big) / 1e6:.0f} MB as .gz (level {level}), written in {time.time() - t0:.0f} s", flush=True)
 for threads in (16, 32, 8, 4):
     dt, got = timed([big], KRISP_PGZIP=1, KRISP_INGEST_THREADS=threads)
     ok = got[0][0].tobytes() == text
