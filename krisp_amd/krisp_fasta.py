@@ -294,6 +294,7 @@ def _merge_groups(device_groups, touched, special_groups):
 
 
 RESERVE_MIN = 128 << 20      # bytes of file text from which the context's memory is made ahead of the uploads (kr_reserve)
+STREAM_MIN = 1 << 30         # ... and from which the files are read one after the other, each on all host threads
 
 
 def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
@@ -310,33 +311,56 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
         labels = [simplename(f) for f in files]
     ingroup_labels = frozenset(simplename(f) for f in ingroup_files)
     flags = [lab in ingroup_labels for lab in labels]
+    try:
+        est = max(fasta.estimate_text_bytes(f) for f in files)
+    except OSError:
+        est = 0
+    ahead = RESERVE_MIN <= est < (1 << 32) - 128 and os.environ.get("KRISP_RESERVE") != "0"
+    # files whose inflate takes every host thread by itself (one large gzip member, a bz2 stream of many blocks) are read
+    # one after the other: the first genome is parsed and sorted on the device while the second still inflates
+    if ahead and est >= STREAM_MIN:
+        workers = 1
     with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device) as eng:
         futures = [pool.submit(fasta.read_text, f) for f in files]
         # large genomes: the context gets its memory (15-40 ms per GB of fresh device memory: seconds at 3 Gbp) while the
         # host threads read and inflate -- planned from the files' sizes, planned again below if they said too little
         planned = 0
-        try:
-            est = max(fasta.estimate_text_bytes(f) for f in files)
-        except OSError:
-            est = 0
-        if RESERVE_MIN <= est < (1 << 32) - 128 and os.environ.get("KRISP_RESERVE") != "0":
+        if ahead:
             planned = est
             eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=planned)
             eng.reserve(list(range(len(files))), planned, with_text=True)
-        first = [fu.result() for fu in futures]            # (the texts' sizes bound the genomes': needed for the sort plan)
-        read_s = time.time() - t0
-        t1 = time.time()
-        true_max = max(max(len(t) for t, _ in first), 1)
-        if true_max > planned:
+        rna, specials = [], []
+        first, t1 = [], None
+        for i, fu in enumerate(futures):
+            text, universal = fu.result()
+            if t1 is None:
+                read_s = time.time() - t0           # (until the first text is there: from then on the device has work)
+                t1 = time.time()
+            if planned and len(text) <= planned and not first:
+                # the plan stands: this genome goes to the device now, the files behind it are still being read
+                _n, r, sp = fasta.ingest_on_device(eng, i, text, universal, k, omit_soft)
+                rna.append(r)
+                specials.append([codec.split_window(w, Le, De, Re) for w in sp])
+                eng.sort(i)
+                del text
+            else:
+                first.append((text, universal))     # (no plan, or a file larger than planned: all sizes first)
+        if first:
+            done = len(files) - len(first)
+            if done:
+                # (a later file said too little about itself: everything again under a plan that holds them all -- the
+                # texts already handed over are read once more)
+                first = [fasta.read_text(f) for f in files[:done]] + first
+                rna, specials = [], []
+            true_max = max(max(len(t) for t, _ in first), 1)
             for i in (range(len(files)) if planned else ()):
                 eng.free(i)
             eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=true_max)
-        rna, specials = [], []
-        for i, (text, universal) in enumerate(first):
-            _n, r, sp = fasta.ingest_on_device(eng, i, text, universal, k, omit_soft)
-            rna.append(r)
-            specials.append([codec.split_window(w, Le, De, Re) for w in sp])
-            eng.sort(i)
+            for i, (text, universal) in enumerate(first):
+                _n, r, sp = fasta.ingest_on_device(eng, i, text, universal, k, omit_soft)
+                rna.append(r)
+                specials.append([codec.split_window(w, Le, De, Re) for w in sp])
+                eng.sort(i)
         t2 = time.time()
         del first
         t3 = time.time()
@@ -359,7 +383,7 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
     # (device_s ends where the context is gone: its buffers freed, the reader threads joined)
     stats = {"read_s": read_s, "device_s": time.time() - t1,
              "kmers": int(sum(counts)) + sum(len(sp) for sp in specials), "candidates": int(ncand),
-             "stage_s": {"parse+sort launches": t2 - t1, "texts freed": t3 - t2, "sorts + intersect": t4 - t3,
+             "stage_s": {"texts arrive, parse + sort launches": t2 - t1, "texts freed": t3 - t2, "sorts + intersect": t4 - t3,
                          "collect": t5 - t4, "context freed": time.time() - t5}}
     if quirk_all_fail:
         return [], stats

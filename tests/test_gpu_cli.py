@@ -897,6 +897,10 @@ def test_memory_reserved_while_the_files_inflate(slice_bases, tmp_path, monkeypa
         s = np.frombuffer(b"ACGT", dtype=np.uint8)[g].tobytes()
         return b">a x\n" + b"\n".join(s[i:i + 70] for i in range(0, 30_000, 70)) + b"\n>b\n" + s[30_000:] + b"\n"
     texts = [genome(s) for s in range(4)]
+    # the last genome is three times as long as the files in front of it let the plan expect (and, as a file of two
+    # members, says even less about itself): the flow plans again -- after three genomes are on the device, or at once
+    filler = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=150_000)].tobytes()
+    texts[3] = texts[3] + b">c\n" + filler + b"\n"
     files = []
     for i, t in enumerate(texts):
         p = tmp_path / f"g{i}{('.fa.gz', '.fa', '.fa.bz2', '.fa.gz')[i]}"
@@ -911,6 +915,7 @@ def test_memory_reserved_while_the_files_inflate(slice_bases, tmp_path, monkeypa
         files.append(str(p))
     assert fasta.estimate_text_bytes(files[0]) == len(texts[0]) and fasta.estimate_text_bytes(files[1]) == len(texts[1])
     assert fasta.estimate_text_bytes(files[3]) < len(texts[3])
+    assert max(fasta.estimate_text_bytes(f) for f in files) < len(texts[3])
     monkeypatch.setenv("KRISP_RESERVE", "0")
     want, _ = KF.find_regions(files[:2], files[2:], 20, 2, 23)
     want = [[(a.left, a.diag, a.right, tuple(a.labels)) for a in g] for g in want]
