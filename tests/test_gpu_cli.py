@@ -376,7 +376,7 @@ from krisp_amd import krisp_fasta as KF
 L, Dg, R = int(os.environ["KR_L"]), int(os.environ["KR_D"]), int(os.environ["KR_R"])
 filt = os.environ["KR_FILTER"] == "1"
 rank, _, world = D.env_rank_world()
-fam = synth.family(21, 3, 3, 1_500_000, records=5, mu=0.004, snp_every=2500, n_frac=0.001, lower_frac=0.01)
+fam = synth.family(21, 3, 3, 1_500_000 if filt else 300_000, records=5, mu=0.004, snp_every=2500, n_frac=0.001, lower_frac=0.01)     # (unfiltered: every conserved flank pair is a group -- a fifth of the size keeps the comparison in seconds)
 names = [nm for nm, _, _ in fam]
 texts = [t for _, _, t in fam]
 mine = D.shard(list(range(len(fam))), rank, world)
@@ -406,7 +406,7 @@ eng.close()
 @pytest.mark.parametrize("world,geo,filt", [(2, (30, 40, 30), True), (3, (30, 40, 30), True), (3, (40, 20, 36), True),
                                             (2, (20, 30, 20), False), (5, (32, 60, 32), True)])
 def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
-    """kr_wide_run with a communicator: 6 genomes of 1.5 Mbp sharded over `world` ranks (sharing cuda:0,
+    """kr_wide_run with a communicator: 6 genomes of 1.5 Mbp (0.3 Mbp without the filter) sharded over `world` ranks (sharing cuda:0,
     file transport): the flank spectra and the group list are intersected over the ranks by the tree
     reduction (lists of millions of entries), every rank locates its own windows, the kept groups'
     mask words travel one 16-column word per round, rank 0 filters on the complete masks and gathers the
