@@ -261,7 +261,7 @@ int64_t kr_read_file(const char* path, uint8_t** text, int64_t* stats);
 /* The large device buffers of `n` genomes (ids[]) of up to n_bases bases each -- upload buffer, sorted-key arrays, sort
  * lanes; with_text: the device reader's copy of the file text as well -- made ahead of the uploads, while host threads
  * still read and inflate the files (krisp_fasta.py:86-123 starts a process per genome; here the one context gets its
- * memory while the files inflate: fresh device memory costs 15-40 ms per GB, seconds at 3 Gbp).  After kr_set_params;
+ * memory while the files inflate: memory another process has just given back costs 15-40 ms per GB to obtain, seconds at 3 Gbp).  After kr_set_params;
  * purely an optimisation: the uploads and sorts make or grow whatever is missing. */
 int kr_reserve(kr_ctx*, const int* ids, int n, size_t n_bases, int with_text);
 int64_t kr_genome_upload_text(kr_ctx*, int id, const uint8_t* text, size_t n, int universal_newlines, int one_shot,

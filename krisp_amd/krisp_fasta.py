@@ -322,7 +322,7 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
         workers = 1
     with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device) as eng:
         futures = [pool.submit(fasta.read_text, f) for f in files]
-        # large genomes: the context gets its memory (15-40 ms per GB of fresh device memory: seconds at 3 Gbp) while the
+        # large genomes: the context gets its memory (device memory another process has just given back takes the driver 15-40 ms per GB to hand over: seconds at 3 Gbp) while the
         # host threads read and inflate -- planned from the files' sizes, planned again below if they said too little
         planned = 0
         if ahead:
