@@ -315,10 +315,10 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
         est = max(fasta.estimate_text_bytes(f) for f in files)
     except OSError:
         est = 0
-    ahead = RESERVE_MIN <= est < (1 << 32) - 128 and os.environ.get("KRISP_RESERVE") != "0"
+    ahead = int(os.environ.get("KRISP_RESERVE_MIN", RESERVE_MIN)) <= est < (1 << 32) - 128 and os.environ.get("KRISP_RESERVE") != "0"
     # files whose inflate takes every host thread by itself (one large gzip member, a bz2 stream of many blocks) are read
     # one after the other: the first genome is parsed and sorted on the device while the second still inflates
-    if ahead and est >= STREAM_MIN:
+    if ahead and est >= int(os.environ.get("KRISP_STREAM_MIN", STREAM_MIN)):
         workers = 1
     with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device) as eng:
         futures = [pool.submit(fasta.read_text, f) for f in files]
