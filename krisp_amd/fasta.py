@@ -118,15 +118,19 @@ def read_text(filename):
 def estimate_text_bytes(path):
     """an estimate from above of a sequence file's text in bytes without reading it (what kr_reserve plans with): the
     file's size; `.gz`: the ISIZE word of its last member plus as many 4 GiB as its compressed size asks for (a file of
-    several members comes out too small: the caller then plans again with the real size); `.bz2`: five times its size"""
+    several members comes out too small: the caller then plans again with the real size; a BGZF file: five times its size);
+    `.bz2`: five times its size"""
     path = os.fspath(path)
     size = os.path.getsize(path)
     if path.endswith(".gz"):
         if size < 18:
             return 0
         with open(path, "rb") as f:
+            head = f.read(18)
             f.seek(size - 4)
             est = int.from_bytes(f.read(4), "little")
+        if len(head) == 18 and head[3] & 4 and head[12:14] == b"BC":
+            return 5 * size              # (BGZF: the last member is the empty end mark; sequence text shrinks 3.3-4.5 x)
         while est < size:
             est += 1 << 32
         return est

@@ -777,6 +777,8 @@ def test_text_size_estimates_for_the_memory_plan(tmp_path):
     fake = blob[:-4] + struct.pack("<I", 100) + b""
     (tmp_path / "big.fa.gz").write_bytes(fake)
     assert fasta.estimate_text_bytes(str(tmp_path / "big.fa.gz")) == 100 + (1 << 32)
+    (tmp_path / "block.fa.gz").write_bytes(_bgzf(t))
+    assert fasta.estimate_text_bytes(str(tmp_path / "block.fa.gz")) == 5 * os.path.getsize(tmp_path / "block.fa.gz")
 
 
 def test_bz2_blocks_decode_side_by_side(tmp_path, monkeypatch):
