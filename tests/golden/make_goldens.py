@@ -213,6 +213,143 @@ def kstream_cases_more():
     return cases
 
 
+def kstream_cases_routes():
+    """Reference vectors for every kstream route the device serves beyond kstream_cases_more() (round 5):
+    every --sort-cols list over 2- and 3-field splits (all permutations, partial and repeated lists, empty fields,
+    split=[a, 0]), --expand-iupac / --allow / kept lower case under --sort, several k with sort columns, k > 32 through
+    kstream -- on inputs with N, lower case, IUPAC letters, RNA and several records -- plus the option sets that stay on
+    the host chain (other disallow sets, N windows surviving, unsorted streams with IUPAC letters, the (last, middle,
+    first) order with unequal outer widths), so that the chain itself is pinned there.  Written to
+    kstream_cases_routes.json.  sort semantics pinned: kstream.py:83-119 runs GNU `sort -t, -kN,N ...`."""
+    import itertools
+    cases = []
+
+    def add(name, kwargs, seqs=None, file_text=None, fname="in.fa", use_write=False):
+        res = run_kstream(kwargs, seqs, file_text, fname, use_write)
+        cases.append({"name": name, "kwargs": kwargs, "seqs": seqs,
+                      "file_text": file_text, "fname": fname,
+                      "use_write": use_write, **res})
+
+    rng = random.Random(505)
+    plain = "ACGT" * 12 + "acgt" * 3 + "Nn"
+    iupac = "ACGT" * 14 + "acgt" * 2 + "Nn" + "RYKMSWBDHVry"
+
+    def fasta(alphabet, nrec, lo, hi):
+        recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(nrec)]
+        return "".join(f">rec{j} d\n{s}\n" for j, s in enumerate(recs))
+
+    texts = [fasta(plain, 3, 8, 36), fasta(iupac, 4, 8, 36), fasta(plain, 2, 20, 44),
+             fasta(iupac, 3, 10, 40).replace("T", "U").replace("t", "u")]
+    strands = [("comp", dict(complements=True)), ("canon", dict(canonicals=True)), ("fwd", {})]
+    softs = [("map", dict(mapsoft=True)), ("omit", dict(omitsoft=True)), ("keep", {})]
+    # ---- A. every column list over 2- and 3-field lines
+    k = 7
+    n = 0
+    for split in ([3], [0], [7], [3, -2], [2, -2], [0, -3], [5, 0], [3, -4]):
+        nf = len(split) + 1
+        lists = [list(p) for r in range(1, nf + 1) for p in itertools.permutations(range(nf), r)]
+        lists += [[0, 0], [1, 0, 1]] if nf == 2 else [[2, 2, 1], [1, 1], [0, 2, 0]]
+        for cols in lists:
+            sname, skw = strands[n % 3]
+            mname, mkw = softs[(n // 3) % 3]
+            kw = dict(kmers=k, disallow="Nn", sort=True, split=split, sortcols=cols, **skw, **mkw)
+            add(f"cols{n}_{sname}_{mname}_{split}_{cols}", kw, file_text=texts[n % len(texts)],
+                fname=f"c{n % len(texts)}.fa", use_write=bool((n // 2) % 2))
+            n += 1
+    # ---- B. --expand-iupac under --sort
+    n = 0
+    for (sname, skw), (mname, mkw) in itertools.product(strands, softs):
+        for split, cols in (((None, None), ([3, -2], [0, 2])) if n % 2 else (([4], [1]), ([2, -3], [2, 1]))):
+            kw = dict(kmers=7, disallow="Nn", sort=True, expandiupac=True, **skw, **mkw)
+            if split is not None:
+                kw["split"] = split
+            if cols is not None:
+                kw["sortcols"] = cols
+            add(f"expand{n}_{sname}_{mname}_{split}_{cols}", kw, file_text=texts[1 + 2 * (n % 2)],
+                fname="e.fa", use_write=bool(n % 3 == 0))
+            n += 1
+    add("expand_no_disallow_sorted", dict(kmers=4, sort=True, expandiupac=True, mapsoft=True), ["ACGNTRAC", "nnAC"])
+    add("expand_unsorted_comp", dict(kmers=5, complements=True, disallow="Nn", expandiupac=True), ["ACGRTYACGT", "ACnGTAACGW"])
+    # ---- C. --allow under --sort
+    n = 0
+    for allow in ("ACGT", "ACGTacgt", "ACGTN", "AC", "ACGTRY", "ATat", "CGNn"):
+        for (sname, skw) in strands:
+            mname, mkw = softs[n % 3]
+            split, cols = [(None, None), ([3, -2], [0, 2]), ([3], [1]), ([2, -3], [1, 0])][n % 4]
+            kw = dict(kmers=5, allow=allow, sort=True, **skw, **mkw)
+            if n % 2:
+                kw["disallow"] = "Nn"
+            if split is not None:
+                kw["split"] = split
+            if cols is not None:
+                kw["sortcols"] = cols
+            add(f"allow{n}_{allow}_{sname}_{mname}_{split}_{cols}", kw, file_text=texts[n % len(texts)],
+                fname="a.fa", use_write=bool(n % 2))
+            n += 1
+    # ---- D. lower case kept (no soft-mask rule) under --sort, heavy lower case
+    lower = "ACGT" * 4 + "acgt" * 4 + "NnRy"
+    ltext = fasta(lower, 3, 12, 40)
+    n = 0
+    for (sname, skw) in strands:
+        for split, cols in ((None, None), ([3, -2], [0, 2]), ([3, -2], [1]), ([2], [1, 0])):
+            kw = dict(kmers=6, disallow="Nn", sort=True, **skw)
+            if split is not None:
+                kw["split"] = split
+            if cols is not None:
+                kw["sortcols"] = cols
+            add(f"keepcase{n}_{sname}_{split}_{cols}", kw, file_text=ltext, fname="l.fa", use_write=bool(n % 2))
+            n += 1
+    # ---- E. several k with sort columns
+    n = 0
+    for ks in ([3, 5], [7, 4, 6], [5, 5], [8, 6]):
+        for split, cols in ((None, None), ([2, -1], [0, 2]), ([3], [1]), ([2, -1], [2, 1, 0]), ([1, -2], [1])):
+            sname, skw = strands[n % 3]
+            mname, mkw = softs[(n // 2) % 3]
+            kw = dict(kmers=ks, disallow="Nn", sort=True, **skw, **mkw)
+            if split is not None:
+                kw["split"] = split
+            if cols is not None:
+                kw["sortcols"] = cols
+            add(f"multik{n}_{ks}_{sname}_{mname}_{split}_{cols}", kw, file_text=texts[n % len(texts)],
+                fname="k.fa", use_write=bool(n % 2))
+            n += 1
+    add("multik_unsorted", dict(kmers=[4, 6], complements=True, disallow="Nn", mapsoft=True, split=[2, -1]),
+        file_text=texts[0], fname="k.fa")
+    # ---- F. k > 32 through kstream (the krisp_fasta combination and its neighbours)
+    longalpha = "ACGT" * 40 + "acgt" * 2 + "N" + "R"
+    for n, (kk, L, R, mname, nrec, lo, hi) in enumerate([(33, 30, 2, "mapsoft", 3, 40, 120), (40, 16, 16, "omitsoft", 3, 50, 140),
+                                                        (100, 30, 30, "mapsoft", 2, 110, 170), (36, 30, 6, "mapsoft", 4, 30, 90),
+                                                        (70, 33, 20, "omitsoft", 2, 80, 150)]):
+        recs = ["".join(rng.choice(longalpha) for _ in range(rng.randint(lo, hi))) for _ in range(nrec)]
+        recs.append(recs[0][5:5 + kk + 6])                      # repeated windows: equal lines
+        text = "".join(f">r{j}\n{s}\n" for j, s in enumerate(recs))
+        if n == 3:
+            text = text.replace("T", "U").replace("t", "u")
+        kw = dict(kmers=kk, complements=True, disallow="Nn", split=[L, -R], sort=True, sortcols=[0, 2])
+        kw[mname] = True
+        add(f"longk{n}_{kk}_{L}_{R}_{mname}", kw, file_text=text, fname="w.fa", use_write=bool(n % 2))
+    lt = "".join(rng.choice("ACGT" * 30 + "N" + "acgt") for _ in range(120))
+    add("longk_fwd_nosplit", dict(kmers=40, disallow="Nn", mapsoft=True, sort=True), [lt])
+    add("longk_canon_split", dict(kmers=35, canonicals=True, disallow="Nn", mapsoft=True, sort=True, split=[10, -10],
+                                  sortcols=[0, 2]), [lt])
+    add("longk_unsorted", dict(kmers=34, complements=True, disallow="Nn", omitsoft=True, split=[12, -12]), [lt])
+    # ---- G. option sets that stay on the host chain
+    t = texts[1]
+    add("host_disallow_other", dict(kmers=5, complements=True, disallow="RrN", mapsoft=True, sort=True), file_text=t, fname="h.fa")
+    add("host_disallow_N_only", dict(kmers=5, disallow="N", sort=True, split=[2, -1], sortcols=[0, 2]), file_text=t, fname="h.fa")
+    add("host_no_disallow_sorted", dict(kmers=5, complements=True, mapsoft=True, sort=True, split=[2, -1], sortcols=[0, 2]),
+        file_text=t, fname="h.fa", use_write=True)
+    add("host_unsorted_iupac", dict(kmers=6, complements=True, disallow="Nn", mapsoft=True, split=[2, -2]), file_text=t, fname="h.fa")
+    add("host_unsorted_keepcase", dict(kmers=6, canonicals=True, disallow="Nn"), file_text=ltext, fname="h.fa")
+    add("host_order_210_unequal", dict(kmers=7, complements=True, disallow="Nn", mapsoft=True, split=[3, -2], sort=True,
+                                        sortcols=[2, 1, 0]), file_text=texts[0], fname="h.fa")
+    add("host_cols_beyond_fields", dict(kmers=6, disallow="Nn", mapsoft=True, split=[3], sort=True, sortcols=[2, 0]),
+        file_text=texts[0], fname="h.fa")
+    add("host_three_splits", dict(kmers=8, disallow="Nn", mapsoft=True, split=[2, 2, -2], sort=True, sortcols=[1, 3]),
+        file_text=texts[0], fname="h.fa")
+    return cases
+
+
 # --------------------------------------------------------------------------
 # 2. krisp_fasta-level cases (stages + final text)
 # --------------------------------------------------------------------------
@@ -415,6 +552,12 @@ def fasta_cases():
 
 
 def main():
+    kr = kstream_cases_routes()
+    with open(HERE / "kstream_cases_routes.json", "w") as f:
+        json.dump(kr, f, indent=1)
+    print(f"kstream cases (routes): {len(kr)}; raised: {sorted(c['name'] for c in kr if 'raises' in c)}")
+    if "--routes-only" in sys.argv:
+        return
     km = kstream_cases_more()
     with open(HERE / "kstream_cases_more.json", "w") as f:
         json.dump(km, f, indent=1)

@@ -61,6 +61,50 @@ def test_kstream_host_chain_on_the_device_served_combinations(case, tmp_path):
     assert list(ks.host_lines(src)) == case["out"]
 
 
+KS_ROUTES = json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json")))
+
+
+@pytest.mark.parametrize("case", KS_ROUTES, ids=lambda c: c["name"])
+def test_kstream_host_chain_on_the_round_4_routes(case, tmp_path):
+    """round 5: every --sort-cols list over 2- and 3-field lines, --expand-iupac / --allow / kept
+    lower case under --sort, several k with sort columns, k > 32 -- the host chain with its GNU-sort emulation
+    (`_host_sorted`), which is what the random differential GPU tests compare the device routes with, against vectors
+    the reference itself produced (real `sort -t, -kN,N`, kstream.py:83-119); the same vectors run on the GPU in
+    test_gpu_cli.py.  Cases named host_* have no device plan on purpose: they pin the chain where it is the product."""
+    src = _src(case, tmp_path)
+    ks = kstream(**case["kwargs"])
+    plan = ks.device_plan()
+    if case["name"].startswith("host_") and "unsorted" not in case["name"]:      # (unsorted: decided from the input at run time)
+        assert plan is None and ks.plan_reason
+    assert list(ks.host_lines(src)) == case["out"]
+    if "count" in case:
+        assert len(case["out"]) == case["count"]
+
+
+def test_route_vectors_cover_what_the_device_plans():
+    """the vectors reach every kind of plan: each key layout, each strand mode, kept case, expansion, allow masks,
+    several k, the wide path"""
+    seen = set()
+    for case in KS_ROUTES:
+        ks = kstream(**case["kwargs"])
+        plan = ks.device_plan()
+        if plan is None:
+            continue
+        for sub in plan.get("multi") or [plan]:
+            seen.add(("layout", sub["layout"]))
+            seen.add(("strands", sub["strands"]))
+            seen.add(("keepcase", sub["keepcase"]))
+            seen.add(("expand", sub["expand"]))
+            seen.add(("allow", sub["allow"] is not None))
+            seen.add(("wide", bool(sub.get("wide"))))
+            seen.add(("nfields", len(sub["fields"])))
+        seen.add(("multi", bool(plan.get("multi"))))
+    want = {("layout", x) for x in ("lrd", "ldr", "custom")} | {("strands", x) for x in (0, 1, 2)} | \
+        {(f, b) for f in ("keepcase", "expand", "allow", "wide", "multi") for b in (False, True)} | \
+        {("nfields", x) for x in (1, 2, 3)}
+    assert want <= seen, want - seen
+
+
 @pytest.mark.parametrize("case", [c for c in KS if "raises" in c or _safe_geometry(c["kwargs"]) is None],
                          ids=lambda c: c["name"])
 def test_kstream_host_chain_matches_reference(case, tmp_path):

@@ -11,7 +11,8 @@ from oracle import krisp_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 KS = json.load(open(os.path.join(GOLDEN, "kstream_cases.json"))) + \
-    json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json")))
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json"))) + \
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json")))
 FC = json.load(open(os.path.join(GOLDEN, "fasta_cases.json")))
 
 
