@@ -120,7 +120,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(config, L, D, R, length, full_length, per_gpu):
+def cpu_baseline(config, L, D, R, length, full_length, per_gpu, gpu_check=None):
     """The packed-key C oracle (oracle/kmer_oracle.c) on a bounded sample of the same workload:
     same generator and parameters, genomes shortened so that the run takes roughly 10-20 s on
     this host (calibrated on 1 Mbp genomes first).  One thread per genome for the sorts -- the
@@ -141,25 +141,35 @@ def cpu_baseline(config, L, D, R, length, full_length, per_gpu):
     replicas = max(1, ncpu // per_gpu)
     cores = min(ncpu, replicas * per_gpu)
 
-    def one_family(fam):
+    kept = {}
+
+    def one_family(fam, keep=False):
         with ThreadPoolExecutor(max_workers=per_gpu) as pool:       # ctypes releases the GIL
             keys = list(pool.map(lambda g: K.sorted_keys(g[2].tobytes(), L, D, R), fam))
         cands = K.intersect(keys, [f for _, f, _ in fam], L, D, R, apply_filter=True)
-        K.collect(keys, cands, L, D, R)
+        recs = K.collect(keys, cands, L, D, R)
+        if keep:
+            kept.update(keys=keys, cands=cands, recs=recs)
         return sum(len(k) for k in keys)
 
-    def run(fam, reps):
+    def run(fam, reps, keep=False):
         t0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=reps) as pool:
-            n = sum(pool.map(lambda _: one_family(fam), range(reps)))
+            n = sum(pool.map(lambda i: one_family(fam, keep and i == 0), range(reps)))
         return time.perf_counter() - t0, n
 
     if length <= 0:
         per_mbp = run(make_genomes(config, 0, 1, per_gpu, 1_000_000), replicas)[0] / per_gpu
         length = int(min(full_length, max(1_000_000, 15.0 / (per_gpu * per_mbp) * 1e6)))
         length -= length % 1_000_000
-    dt, n = run(make_genomes(config, 0, 1, per_gpu, length), replicas)
-    out = {"value": n / dt, "unit": "k-mers/s", "cores": cores, "cores_on_host": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
+    full = gpu_check is not None and length == full_length
+    dt, n = run(make_genomes(config, 0, 1, per_gpu, length), replicas, keep=full)
+    # the sample IS the benchmarked workload (same generator, same length): its sorted keys, candidates and records are
+    # compared with what the GPU left behind after the timed steps, bit for bit (`oracle_match`)
+    match = gpu_check(kept) if full else {"checked": False, "why": f"the CPU sample ({length / 1e6:g} Mbp genomes) is "
+                                          f"shorter than the benchmarked workload ({full_length / 1e6:g} Mbp)"}
+    kept.clear()
+    out = {"oracle_match": match, "value": n / dt, "unit": "k-mers/s", "cores": cores, "cores_on_host": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
            "sample": f"{replicas} side-by-side replica(s) of {per_gpu} x {length / 1e6:g} Mbp genomes of the same "
                      f"generator, {L}/{D}/{R}, {n} k-mers in {dt:.1f} s (oracle/kmer_oracle.c: generate + LSD radix "
                      f"sort, one thread per genome; n-way intersect + filter + collect on one thread per replica); {cores} of the host's "
@@ -433,7 +443,14 @@ def main():
     dt = time.perf_counter() - t0
     stages = eng.stage_times() if not args.no_stage_timers else {}
     kmers_local = int(sum(eng.wide_fetch(_native.WIDE_COUNTS))) if wide else sum(eng.count(g) for g in ids)
-    copy_gbps = eng.copy_gbps(1 << 30, 10) if rank == 0 else None      # measured streaming-copy rate of this box
+    # measured streaming-copy rate of this box: the best of every copy form x grid the library times (kr_debug_copy_gbps),
+    # over 1 GiB and over 800 MB arrays (the size of a genome's key array)
+    copy_gbps, copy_which = None, None
+    if rank == 0:
+        for nb in (1 << 30, 800_000_000):
+            v = eng.copy_gbps(nb, 10)
+            if copy_gbps is None or v > copy_gbps:
+                copy_gbps, copy_which = v, eng.copy_which()
 
     if comm and world > 1:
         dt = float(eng.comm_allreduce([dt], "max")[0])
@@ -441,6 +458,25 @@ def main():
         records_total = int(eng.comm_allreduce([float(nrec[0])], "sum")[0])
     else:
         kmers_total, records_total = kmers_local, nrec[0]
+
+    def gpu_check(want):
+        """the oracle's sorted keys / candidates / records of the full workload against what the last timed step left in
+        HBM (bench.py's checker leg: the oracle is never on the timed path)"""
+        import numpy as np
+        res = {"checked": True, "what": "sorted keys of every genome, candidates (prefix, ingroup / outgroup masks) and records "
+                                        "of the last timed step == oracle/kmer_oracle.c on the same genomes, bit for bit"}
+        try:
+            ok_keys = all(np.array_equal(eng.keys(g), want["keys"][i]) for i, g in enumerate(ids))
+            got = eng.cands()
+            ok_c = len(got) == len(want["cands"]) and all(np.array_equal(got[f], want["cands"][f]) for f in ("prefix", "in_mask", "out_mask"))
+            recs = np.sort(eng.fetch_records(nrec[0]), order=["key", "genome"])
+            wrec = np.sort(want["recs"], order=["key", "genome"])
+            ok_r = np.array_equal(recs, wrec)
+            res.update(sorted_keys=bool(ok_keys), candidates=bool(ok_c), records=bool(ok_r), match=bool(ok_keys and ok_c and ok_r),
+                       n_candidates=int(len(got)), n_records=int(len(recs)))
+        except Exception as e:  # noqa: BLE001
+            res.update(match=False, error=str(e))
+        return res
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -504,7 +540,7 @@ def main():
                     "how": "algorithmic bytes per launch / average launch time (HIP events on the library's stream around each "
                            "launch) of the dominant kernel by itself: calibration steps of this run with one sort lane",
                     "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(alone / copy_gbps, 4),
-                    "copy_peak_guide": 6290.0,
+                    "copy_peak_which": copy_which, "copy_peak_guide": 6290.0,
                     "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
                     "live": {"what": f"the same kernel inside the timed region ({lanes} sort lane(s)"
                                      + ("" if lanes <= 1 or wide else ": its launches run beside the kernels of other genomes' "
@@ -518,6 +554,10 @@ def main():
                     "stage_ms_per_step_calibration": {s: round(v[0], 4) for s, v in calib.items()}}
         name = baseline_config_name(cfg, custom, world, args.independent, args.masked, args.mu, args.records, args.snp_every)
         out = {
+            # schema 5 (round 5): as round 4 (`roofline` top level = the dominant kernel by itself, `roofline.live` = the same
+            # kernel inside the timed region, `roofline.step` = all kernels on measured bytes) + `copy_peak_which`,
+            # `config.baseline_config_index`, `oracle_match`
+            "schema": 5,
             "metric": f"k-mers/s sorted+intersected at k={k}", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -529,7 +569,8 @@ def main():
                                    + (", independent genomes" if args.independent else "")
                                    + (", 0.1 % N runs + 5 % lower case" if args.masked else "")
                                    + f"), {L}/{Dg}/{R} (k={k})",
-                       "baseline_config": name, "baseline_text": None if custom else C["what"],
+                       "baseline_config": name, "baseline_config_index": None if custom else cfg,
+                       "baseline_text": None if custom else C["what"],
                        "step": ("one kr_wide_run: flank spectrum + dictionaries + composite keys, sort + n-way intersect, "
                                 "locate + filter + hits (resident in HBM)") if wide else
                                "sort every genome + n-way intersect + filter"
@@ -543,7 +584,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and wide:
             out["cpu_baseline"] = cpu_baseline_wide(config, L, Dg, R, per_gpu, args.mu, args.records, args.snp_every)
         elif world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(config, L, Dg, R, args.cpu_length, length, per_gpu)
+            check = gpu_check if gen_8d and not args.no_collect else None      # (the CPU sample is 8(d)'s generator)
+            out["cpu_baseline"] = cpu_baseline(config, L, Dg, R, args.cpu_length, length, per_gpu, gpu_check=check)
+            out["oracle_match"] = out["cpu_baseline"].pop("oracle_match", None)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

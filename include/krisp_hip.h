@@ -264,6 +264,11 @@ int64_t kr_read_file(const char* path, uint8_t** text, int64_t* stats);
  * memory while the files inflate: memory another process has just given back costs 15-40 ms per GB to obtain, seconds at 3 Gbp).  After kr_set_params;
  * purely an optimisation: the uploads and sorts make or grow whatever is missing. */
 int kr_reserve(kr_ctx*, const int* ids, int n, size_t n_bases, int with_text);
+/* out4[0] = bytes this context may still allocate (the device's free memory, or the rest of its HBM budget when that is
+ * less), [1] = the device's total, [2] = bytes the context holds, [3] = its budget (0 = none).  The command line sizes its
+ * genome batches with it when a genome set does not fit one GPU (krisp_amd/krisp_fasta.py: the streaming flow -- the
+ * reference has no such limit: kstream.py:108-119 sorts in external memory, intersectAmplicons.py:232-310 merges files) */
+int kr_mem_info(kr_ctx*, int64_t* out4);
 int64_t kr_genome_upload_text(kr_ctx*, int id, const uint8_t* text, size_t n, int universal_newlines, int one_shot,
                               int64_t* stats);
 int64_t kr_genome_fetch_bases(kr_ctx*, int id, uint8_t* out, size_t cap);
@@ -356,6 +361,9 @@ double  kr_debug_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t*
 /* measured streaming-copy rate of this device (read + write GB/s): bench.py reports the roofline
  * fraction against it beside the 8 TB/s specification figure */
 double  kr_debug_copy_gbps(kr_ctx*, size_t bytes, int reps);
+/* which copy form and grid gave that figure (1 / 2 / 4 loads in flight per lane, plain or non-temporal, 2 .. 32 workgroups
+ * per CU are all timed; the best is reported): a string owned by the context, valid until the next probe */
+const char* kr_debug_copy_which(kr_ctx*);
 /* the pipelined intersect kernels: items that went to the chunk kernel (oversized), slices redone by chunks,
  * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
  * now; out[6..7] = 0 */

@@ -107,6 +107,8 @@ SYMBOLS = [
     ("kr_debug_localsort", _c.c_double, [_P, _c.c_int, _c.c_int, _c.c_int]),
     ("kr_debug_intersect", _c.c_double, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_int]),
     ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
+    ("kr_debug_copy_which", _c.c_char_p, [_P]),
+    ("kr_mem_info", _c.c_int, [_P, _P]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
     ("kr_render_records", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _c.c_size_t, _P,
                                        _c.c_int, _P, _P, _P, _P]),
@@ -118,7 +120,12 @@ SYMBOLS = [
 
 
 class KrispHipError(RuntimeError):
-    pass
+    """a negative return code of the library with kr_last_error's text; `.code` = the KR_ERR_* value (-3 = capacity:
+    a caller buffer, the context's HBM budget or the device's memory does not hold what was asked for)"""
+    code = None
+
+
+ERR_CAPACITY = -3
 
 
 _lib = None
@@ -340,7 +347,9 @@ class Engine:
 
     def _check(self, rc, what):
         if rc < 0:
-            raise KrispHipError(f"{what}: [{rc}] " + self.lib.kr_last_error(self.ctx).decode())
+            e = KrispHipError(f"{what}: [{rc}] " + self.lib.kr_last_error(self.ctx).decode())
+            e.code = int(rc)
+            raise e
         return rc
 
     # ---- configuration
@@ -592,6 +601,16 @@ class Engine:
         if v < 0:
             raise KrispHipError("kr_debug_copy_gbps failed")
         return v
+
+    def mem_info(self):
+        """bytes this context may still allocate (device free memory / rest of its budget), device total, held, budget"""
+        o = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.kr_mem_info(self.ctx, _ptr(o)), "kr_mem_info")
+        return dict(avail=int(o[0]), total=int(o[1]), used=int(o[2]), budget=int(o[3]))
+
+    def copy_which(self):
+        """the copy form and grid the latest copy_gbps() found fastest"""
+        return (self.lib.kr_debug_copy_which(self.ctx) or b"").decode()
 
     def inversions(self, gid):
         return self._check(self.lib.kr_debug_inversions(self.ctx, gid), "kr_debug_inversions")

@@ -318,17 +318,50 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
     ahead = int(os.environ.get("KRISP_RESERVE_MIN", RESERVE_MIN)) <= est < (1 << 32) - 128 and os.environ.get("KRISP_RESERVE") != "0"
     # files whose inflate takes every host thread by itself (one large gzip member, a bz2 stream of many blocks) are read
     # one after the other: the first genome is parsed and sorted on the device while the second still inflates
-    if ahead and est >= int(os.environ.get("KRISP_STREAM_MIN", STREAM_MIN)):
+    # (plain text files use no inflate threads: they keep their readers side by side -- ADVICE r4)
+    if ahead and est >= int(os.environ.get("KRISP_STREAM_MIN", STREAM_MIN)) and \
+            any(str(f).lower().endswith((".gz", ".bz2", ".bgz")) for f in files):
         workers = 1
-    with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device) as eng:
+    budget = int(os.environ.get("KRISP_HBM_BUDGET", "0"))       # (bytes; tests and shared devices: kr_create's HBM budget)
+    with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device, hbm_budget=budget) as eng:
+        # a genome set the device cannot hold sorted at once goes through it in batches (the streaming flow above)
+        batch = _plan_batch(eng, len(files), est) if len(files) > 1 else None
+        if batch is not None:
+            t1 = time.time()
+            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(est, 1))
+            records, touched, sgroups, all_rna, stats = _find_regions_streaming(
+                eng, pool, files, labels, flags, k, geo, omit_soft, verbose, do_filter, quirk_all_fail, batch, t0, max(est, 1))
+            stats["device_s"] = time.time() - t1
+            if quirk_all_fail:
+                return [], stats
+            if not touched and not all_rna:
+                return amplicon.RecordGroups(records, labels, Le, De, Re), stats
+            groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
+            if touched:
+                groups = _merge_groups(groups, touched, sgroups)
+            return (_to_rna(groups) if all_rna else groups), stats
         futures = [pool.submit(fasta.read_text, f) for f in files]
         # large genomes: the context gets its memory (device memory another process has just given back takes the driver 15-40 ms per GB to hand over: seconds at 3 Gbp) while the
         # host threads read and inflate -- planned from the files' sizes, planned again below if they said too little
         planned = 0
         if ahead:
+            # kr_reserve is an optimisation (include/krisp_hip.h), and the plan is an ESTIMATE from the files' sizes (5 x
+            # the compressed bytes where real sequence text is 3.3-4.5 x): a reservation that does not fit says nothing
+            # about the run itself -- the reserved buffers go back and the unplanned flow below sizes the context from the
+            # texts once they are read
             planned = est
-            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=planned)
-            eng.reserve(list(range(len(files))), planned, with_text=True)
+            try:
+                eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=planned)
+                eng.reserve(list(range(len(files))), planned, with_text=True)
+            except _native.KrispHipError as e:
+                if verbose:
+                    print(f"=> memory plan for {planned:,} bases per genome not taken ({e}): sizing from the texts instead", file=sys.stderr)
+                for i in range(len(files)):
+                    try:
+                        eng.free(i)
+                    except _native.KrispHipError:
+                        pass
+                planned = 0
         rna, specials = [], []
         first, t1 = [], None
         for i, fu in enumerate(futures):
@@ -393,6 +426,178 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
     if touched:
         groups = _merge_groups(groups, touched, sgroups)
     return finish(groups), stats
+
+
+# ----------------------------------------------------------------------------
+# genome sets larger than one GPU's memory: the streaming flow (SURVEY section 7 "HBM sizing")
+# ----------------------------------------------------------------------------
+STREAM_EAGER_MAX = 4_000_000     # running candidates up to which a batch's records are collected at once (64 MB per genome)
+
+
+def _plan_batch(eng, nfiles, est_bases):
+    """How many genomes of ~est_bases the context can hold sorted at once beside its scratch (None: all of them).  Per
+    genome: the bases and two 8-byte keys per base (+ 2 % slack for key-space slices); scratch: codes + pass-1 output
+    per sort lane (three at most), the pass-0 array of two genome lanes when the genome is sorted in slices (> 2^28
+    bases), the text buffer of the device reader, candidate buffers.  KRISP_STREAM_BATCH=n forces batches of n."""
+    forced = os.environ.get("KRISP_STREAM_BATCH")
+    if forced:
+        return max(1, int(forced)) if int(forced) < nfiles else None
+    if est_bases <= 0:
+        return None
+    per_genome = 17.4 * est_bases
+    sliced = est_bases > (1 << 28)
+    scratch = (2 * 16.2 * est_bases + 3 * 17.0 * est_bases / 16) if sliced else 3 * 17.0 * est_bases
+    scratch += est_bases + (2 << 30)
+    avail = eng.mem_info()["avail"]
+    fit = int((avail - scratch) // per_genome)
+    if fit >= nfiles:
+        return None
+    return max(1, fit)
+
+
+def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, verbose, do_filter, quirk_all_fail, batch, t0,
+                            max_bases):
+    """find_regions for a genome set that does not fit the GPU at once (the reference has no such limit: it sorts in
+    external memory, kstream.py:108-119, and merges files pairwise, intersectAmplicons.py:232-310).  The genomes go
+    through the device in batches of `batch`: sort the batch, intersect it (with the diagnostic filter: the predicate
+    is monotone, so a batch may prune with its partial masks -- in and out genomes are interleaved so that every batch
+    holds both), merge the batch's candidates into the running set (list n list, masks OR-ed: kr_cands_merge), collect
+    the batch's records of the running candidates (a superset of the final ones) and free the batch.  The records of
+    the final candidates are what remains of those; only when the running set was too large to collect from (no
+    outgroup, no filter: every conserved pair is a candidate) or IUPAC windows touch groups whose ACGT members must be
+    looked up, a second pass sorts every batch again and collects then.  Same records, same order, same text as the
+    in-core flow (tests/test_gpu_cli.py)."""
+    from . import _native
+    Le, De, Re = geo
+    n = len(files)
+    ing = [i for i in range(n) if flags[i]]
+    outg = [i for i in range(n) if not flags[i]]
+    order = []
+    for j in range(max(len(ing), len(outg))):
+        order += ing[j:j + 1] + outg[j:j + 1]
+    apply_f = do_filter and not quirk_all_fail
+    rank_of = {g: r for r, g in enumerate(sorted(range(n), key=lambda i: labels[i]))}
+    rna, specials, counts = [None] * n, [None] * n, [0] * n
+    pmask = np.uint64((~0 << (64 - 2 * (Le + Re))) & 0xFFFFFFFFFFFFFFFF) if Le + Re < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    stats = {"streamed": True, "batch": batch, "passes": 1, "batches": 0}
+    read_s = [None]
+    maxb = [max_bases]
+
+    def batches(bsz):
+        for a in range(0, n, bsz):
+            yield order[a:a + bsz]
+
+    def load_batch(ids_b, futs, first_pass):
+        """texts -> device, sorted; a batch that does not fit after all is given back whole (KrispHipError, code capacity)"""
+        done = []
+        texts = {g: futs[g].result() for g in ids_b}
+        if read_s[0] is None:
+            read_s[0] = time.time() - t0
+        biggest = max(len(t) for t, _ in texts.values())
+        if biggest > maxb[0]:
+            # (the plan came from the files' sizes: a text longer than it said -- nothing is resident between batches)
+            maxb[0] = biggest
+            eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=biggest)
+        try:
+            for g in ids_b:
+                text, universal = texts.pop(g)
+                _n, r, sp = fasta.ingest_on_device(eng, g, text, universal, k, omit_soft)
+                del text
+                done.append(g)
+                if first_pass:
+                    rna[g] = r
+                    specials[g] = [codec.split_window(w, Le, De, Re) for w in sp]
+                eng.sort(g)
+            for g in ids_b:
+                counts[g] = eng.count(g)
+        except _native.KrispHipError:
+            for g in done:
+                eng.free(g)
+            raise
+
+    def run_pass(bsz, first_pass, work):
+        """every batch through load_batch + work(ids_b); the next batch's files are read while this one is on the device;
+        a batch the device cannot hold is halved and tried again (the plan is an estimate)"""
+        todo = list(batches(bsz))
+        futs = {}
+        while todo:
+            ids_b = todo.pop(0)
+            for g in ids_b + (todo[0] if todo else []):
+                if g not in futs:
+                    futs[g] = pool.submit(fasta.read_text, files[g])
+            try:
+                load_batch(ids_b, futs, first_pass)
+            except _native.KrispHipError as e:
+                if e.code != _native.ERR_CAPACITY or len(ids_b) == 1:
+                    raise
+                half = (len(ids_b) + 1) // 2
+                todo = [ids_b[:half], ids_b[half:]] + todo
+                for g in ids_b:
+                    futs[g] = pool.submit(fasta.read_text, files[g])
+                stats["batch"] = min(stats["batch"], half)
+                continue
+            work(ids_b)
+            for g in ids_b:
+                eng.free(g)
+                del futs[g]
+            stats["batches"] += 1
+
+    running = [None]
+    eager = [True]
+    kept = []
+
+    def pass1(ids_b):
+        bflags = [flags[g] for g in ids_b]
+        eng.intersect(ids_b, bflags, apply_filter=apply_f)
+        if running[0] is not None:
+            eng.merge_cands(running[0], apply_filter=apply_f)
+        running[0] = eng.cands().copy()
+        if verbose:
+            for g in ids_b:
+                print(f"=> Extracted and sorted {counts[g]:,} {k}-kmers from {files[g]}", file=sys.stderr)
+        if quirk_all_fail or not len(running[0]):
+            return
+        if eager[0] and len(running[0]) <= STREAM_EAGER_MAX:
+            kept.append(eng.collect(sorted(ids_b, key=lambda g: rank_of[g])))
+        else:
+            eager[0] = False
+            kept.clear()
+
+    run_pass(batch, True, pass1)
+    final = running[0] if running[0] is not None else np.empty(0, dtype=_native.CAND)
+    if any(rna) and not all(rna):
+        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+    touched = {(l, r) for sp in specials for (l, d, r) in sp} if not quirk_all_fail else set()
+    pure = sorted({_prefix_key(l, r) for (l, r) in touched if _pure(l) and _pure(r)})
+    srecs = []
+    if (len(final) and not eager[0] and not quirk_all_fail) or pure:
+        stats["passes"] = 2
+        tc = np.zeros(len(pure), dtype=_native.CAND)
+        tc["prefix"] = np.array(pure, dtype=np.uint64)
+
+        def pass2(ids_b):
+            by = sorted(ids_b, key=lambda g: rank_of[g])
+            if len(final) and not eager[0]:
+                eng.load_cands(final)
+                kept.append(eng.collect(by))
+            if pure:
+                eng.load_cands(tc)
+                srecs.append(eng.collect(by))
+        run_pass(max(1, stats["batch"]), False, pass2)
+    if kept and len(final):
+        records = np.concatenate(kept)
+        records = records[np.isin(records["key"] & pmask, final["prefix"])]
+        ranks = np.array([rank_of[g] for g in range(n)], dtype=np.int64)[records["genome"]]
+        records = records[np.lexsort((ranks, records["key"]))]
+    else:
+        records = np.empty(0, dtype=_native.RECORD)
+    sgroups = []
+    if touched:
+        recs = np.concatenate(srecs) if srecs else None
+        sgroups = _special_groups_from(recs, list(range(n)), labels, specials, geo, frozenset(l for l, f in zip(labels, flags) if f),
+                                       do_filter)
+    stats.update(read_s=read_s[0] or 0.0, kmers=int(sum(counts)) + sum(len(sp) for sp in specials), candidates=int(len(final)))
+    return records, touched, sgroups, all(rna), stats
 
 
 # ----------------------------------------------------------------------------

@@ -930,3 +930,80 @@ def test_memory_reserved_while_the_files_inflate(slice_bases, tmp_path, monkeypa
             assert got == want
         else:
             assert len(got) >= 1
+
+
+def _render_groups(groups, ingroup_labels):
+    """final text; for groups with IUPAC letters (the reference's renderer raises on a lone ambiguity letter in a column,
+    Amplicon.py:65, and so does ours) the merged-file lines"""
+    from krisp_amd import amplicon
+    try:
+        return amplicon.render(groups, ingroup_labels)
+    except KeyError:
+        return amplicon.merged_lines(groups)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["filter", "no_outgroup_two_passes", "iupac", "rna", "slices"])
+def test_streaming_flow_equals_the_in_core_flow(case, tmp_path, monkeypatch):
+    """round 5 (SURVEY section 7 "HBM sizing"): a genome set that does not fit the GPU goes through it
+    in batches -- sort the batch, intersect + filter, merge into the running candidates, collect, free
+    (krisp_fasta._find_regions_streaming).  Six genomes with N runs, lower case, duplicated regions: batches of 1, 2, 4
+    (KRISP_STREAM_BATCH), and the automatic plan under an HBM budget (kr_mem_info), give the in-core flow's groups and
+    text byte for byte -- with the filter (records collected batch by batch), without an outgroup and a running set above
+    the eager limit (second pass), with IUPAC windows (second pass for the groups they touch), RNA input, key-space
+    slices.  The reference has no such limit: kstream.py:108-119, intersectAmplicons.py:232-310."""
+    import numpy as np
+    from krisp_amd import krisp_fasta as KF
+    rng = np.random.default_rng({"filter": 1, "no_outgroup_two_passes": 2, "iupac": 3, "rna": 4, "slices": 5}[case])
+    G = 40_000
+    anc = rng.integers(0, 4, size=G)
+    anc[5000:5300] = anc[1000:1300]                                  # a duplicated region: counts above one
+    snps = rng.choice(np.arange(100, G - 100), size=60, replace=False)
+    files = []
+    for gi in range(6):
+        g = anc.copy()
+        at = rng.integers(0, G, size=300)
+        g[at] = (g[at] + 1 + rng.integers(0, 3, size=300)) % 4
+        is_in = gi < 3
+        g[snps] = (anc[snps] + (1 if is_in else 2)) % 4               # planted ingroup / outgroup bases
+        s = bytearray(np.frombuffer(b"ACGT", dtype=np.uint8)[g].tobytes())
+        a = int(rng.integers(0, G - 400))
+        s[a:a + 200] = bytes(s[a:a + 200]).lower()
+        b = int(rng.integers(0, G - 400))
+        s[b:b + 50] = b"N" * 50
+        if case == "iupac":
+            for p in rng.integers(0, G, size=6):
+                s[int(p)] = ord(rng.choice(list("RYKMSW")))
+            for p in snps[:3]:                                       # ... also right beside planted sites
+                s[int(p) + 3] = ord("R")
+        t = bytes(s)
+        if case == "rna":
+            t = t.replace(b"T", b"U").replace(b"t", b"u")
+        p = tmp_path / f"{'in' if is_in else 'out'}{gi}.fa"
+        p.write_bytes(b">a\n" + b"\n".join(t[i:i + 80] for i in range(0, G // 2, 80)) + b"\n>b x\n" + t[G // 2:] + b"\n")
+        files.append(str(p))
+    ing, outg = (files, []) if case == "no_outgroup_two_passes" else (files[:3], files[3:])
+    L, D, R = (12, 1, 6) if case != "no_outgroup_two_passes" else (14, 0, 10)
+    k = L + D + R
+    if case == "slices":
+        monkeypatch.setenv("KR_SLICE_BASES", "1")
+    labels = [KF.simplename(f) for f in ing]
+    want, wstats = KF.find_regions(ing, outg, L, R, k)
+    assert not wstats.get("streamed")
+    want_text = _render_groups(want, labels)
+    assert wstats["candidates"] >= 20
+    if case == "no_outgroup_two_passes":
+        monkeypatch.setattr(KF, "STREAM_EAGER_MAX", 10)
+    for batch in ("1", "2", "4"):
+        monkeypatch.setenv("KRISP_STREAM_BATCH", batch)
+        got, stats = KF.find_regions(ing, outg, L, R, k)
+        assert stats["streamed"] and stats["batch"] == int(batch) and stats["candidates"] == wstats["candidates"]
+        assert stats["kmers"] == wstats["kmers"]
+        assert stats["passes"] == (2 if case in ("no_outgroup_two_passes", "iupac") else 1), stats
+        assert _render_groups(got, labels) == want_text, (case, batch)
+    monkeypatch.delenv("KRISP_STREAM_BATCH")
+    # the automatic plan: a budget that holds the scratch and about two genomes
+    monkeypatch.setenv("KRISP_HBM_BUDGET", str((2 << 30) + int(3 * 17.0 * G * 1.3) + int(2.5 * 17.4 * G * 1.3)))
+    got, stats = KF.find_regions(ing, outg, L, R, k)
+    assert stats["streamed"] and 1 <= stats["batch"] < 6, stats
+    assert _render_groups(got, labels) == want_text

@@ -104,6 +104,47 @@ def test_c2_full_size_properties():
     assert np.array_equal(c1, c4)
 
 
+def test_c2_full_size_equals_the_oracle():
+    """BASELINE configs[1] at the size the bench quotes (4 x 50 Mbp of SURVEY 8(d)'s generator, 25/1/2), bit for bit against
+    the packed-key oracle (oracle/kmer_oracle.c: ~6 s with a thread per genome): every genome's sorted keys, the candidates
+    with their masks, the records (the properties above are no longer the only check at this size)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from krisp_amd import _native
+    from oracle import kmer_oracle as K
+    K.build()
+    L, D, R = 25, 1, 2
+    fam = _family(2, 2, 2, 50_000_000)
+    flags = [f for _, f, _ in fam]
+    with ThreadPoolExecutor(max_workers=len(fam)) as pool:          # (ctypes releases the GIL)
+        want_keys = list(pool.map(lambda g: K.sorted_keys(g[2].tobytes(), L, D, R), fam))
+    want = K.intersect(want_keys, flags, L, D, R, apply_filter=True)
+    wrec = np.sort(K.collect(want_keys, want, L, D, R), order=["key", "genome"])
+    with _native.Engine() as eng:
+        eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        ids = list(range(len(fam)))
+        for i, (_, _, t) in enumerate(fam):
+            eng.upload(i, t)
+        for i in ids:
+            eng.sort(i)
+        for i in ids:
+            got = eng.keys(i)
+            assert len(got) == len(want_keys[i]) and np.array_equal(got, want_keys[i]), f"sorted keys of genome {i} differ"
+            del got
+        n = eng.intersect(ids, flags, apply_filter=True)
+        got = eng.cands()
+        assert n == len(want) > 1000
+        for f in ("prefix", "in_mask", "out_mask"):
+            assert np.array_equal(got[f], want[f]), f
+        recs = np.sort(eng.collect(ids), order=["key", "genome"])
+        assert np.array_equal(recs, wrec)
+        # and without the filter: every conserved (left,right) pair of the four genomes
+        want_all = K.intersect(want_keys, flags, L, D, R, apply_filter=False)
+        assert eng.intersect(ids, flags, apply_filter=False) == len(want_all)
+        got = eng.cands()
+        for f in ("prefix", "in_mask", "out_mask"):
+            assert np.array_equal(got[f], want_all[f]), f
+
+
 BIG = pytest.mark.skipif(os.environ.get("KR_SKIP_BIG") == "1", reason="KR_SKIP_BIG=1")
 
 

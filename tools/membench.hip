@@ -230,6 +230,26 @@ int main() {
         }
         printf("  GB/s\n");
     }
+    // round 5: the same write-only pattern with longer runs (what a pass 1 with 16384- / 32768-key tiles would write)
+    {
+        auto wo = [&](auto tag, u32 run_bytes) {
+            constexpr int RUN16 = decltype(tag)::value;
+            const u32 ntiles = (u32)(N16 / (256 * RUN16));
+            const u64 bucket16 = (u64)ntiles * RUN16;
+            for (int grid : {256, 512}) {
+                printf("write-only, runs %4u B, 8-B stores, %d workgroups:", run_bytes, grid);
+                for (u32 shift8 : {0u, 1u, 4u, 8u}) {
+                    double t = timeit([&] { hipLaunchKernelGGL((k_scatter<RUN16, 1, 1>), dim3(grid), dim3(1024), 0, 0, a, b, ntiles, bucket16, shift8, 0u); }, 5);
+                    printf("  +%2u B: %4.0f", shift8 * 8, 1.0 * (u64)ntiles * 256 * RUN16 * 16 / t / 1e6);
+                }
+                printf("  GB/s\n");
+            }
+        };
+        wo(std::integral_constant<int, 16>{}, 256);
+        wo(std::integral_constant<int, 32>{}, 512);
+        wo(std::integral_constant<int, 64>{}, 1024);
+        wo(std::integral_constant<int, 128>{}, 2048);
+    }
     // packed 5-byte keys: pass 2's pattern (16384-key tiles, 256 runs of 64 keys) written as 320-byte runs on any byte
     // boundary against the 512-byte runs of 8-byte keys above; and a streaming read of the packed array
     {
