@@ -435,10 +435,12 @@ def main():
         step()
         eng.stage_reset()
         barrier()
+    comm0 = eng.debug_comm() if comm else None
     t0 = time.perf_counter()
     ncand = 0
     for _ in range(args.steps):
         ncand = step()
+    comm1 = eng.debug_comm() if comm else None      # (before the closing barrier: that is bench.py's, not the step's)
     barrier()
     dt = time.perf_counter() - t0
     stages = eng.stage_times() if not args.no_stage_timers else {}
@@ -563,6 +565,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "rccl_ranks": eng.comm_rccl_ranks(),     # (ncclCommCount: 0 = no RCCL communicator in this run)
+            # the ONE exchange of a step on rank 0 (kr_debug_comm): blocking calls and host time inside kr_cands_reduce +
+            # kr_cands_bcast (the time includes waiting for the slowest rank's sorts: the tree is the step's first meeting)
+            "exchange": None if not comm or world == 1 else {
+                "ms_per_step": round((comm1["exchange_us"] - comm0["exchange_us"]) / args.steps / 1e3, 4),
+                "host_syncs_per_step": (comm1["syncs"] - comm0["syncs"]) / args.steps,
+                "p2p_calls_per_step": (comm1["p2p"] - comm0["p2p"]) / args.steps,
+                "collectives_per_step": (comm1["collectives"] - comm0["collectives"]) / args.steps,
+                "message_entries": comm1["message_entries"], "transport": args.transport},
             "config": {"workload": f"{name}: {per_gpu} synthetic {length / 1e6:g} Mbp random "
                                    f"genomes per GPU (half in / half out over the {per_gpu * world}-genome "
                                    f"family, mu={args.mu:g}, {args.records} records, planted SNP / {args.snp_every}"

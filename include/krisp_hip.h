@@ -368,6 +368,10 @@ const char* kr_debug_copy_which(kr_ctx*);
  * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
  * now; out[6..7] = 0 */
 int     kr_debug_isect(kr_ctx*, int64_t* out8);
+/* what the multi-GPU exchange has cost this context so far: out[0] host synchronisations, [1] point-to-point calls,
+ * [2] collectives, [3] microseconds inside kr_cands_reduce / kr_cands_bcast, [4] kr_cands_reduce calls, [5] entries of the
+ * agreed message size */
+int     kr_debug_comm(kr_ctx*, int64_t* out8);
 /* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
 int64_t kr_debug_budget_left(kr_ctx*);
 int     kr_debug_budget_set(kr_ctx*, int64_t left);

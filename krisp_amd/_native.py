@@ -109,6 +109,7 @@ SYMBOLS = [
     ("kr_debug_copy_gbps", _c.c_double, [_P, _c.c_size_t, _c.c_int]),
     ("kr_debug_copy_which", _c.c_char_p, [_P]),
     ("kr_mem_info", _c.c_int, [_P, _P]),
+    ("kr_debug_comm", _c.c_int, [_P, _P]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
     ("kr_render_records", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _c.c_size_t, _P,
                                        _c.c_int, _P, _P, _P, _P]),
@@ -607,6 +608,13 @@ class Engine:
         o = np.zeros(4, dtype=np.int64)
         self._check(self.lib.kr_mem_info(self.ctx, _ptr(o)), "kr_mem_info")
         return dict(avail=int(o[0]), total=int(o[1]), used=int(o[2]), budget=int(o[3]))
+
+    def debug_comm(self):
+        """what the multi-GPU exchange has cost so far (kr_debug_comm)"""
+        o = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.kr_debug_comm(self.ctx, _ptr(o)), "kr_debug_comm")
+        return dict(syncs=int(o[0]), p2p=int(o[1]), collectives=int(o[2]), exchange_us=int(o[3]), reduces=int(o[4]),
+                    message_entries=int(o[5]))
 
     def copy_which(self):
         """the copy form and grid the latest copy_gbps() found fastest"""

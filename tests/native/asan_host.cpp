@@ -1,11 +1,18 @@
 // Host-only build of the library's text code (krisp_amd/csrc/h_text.inc: FASTA parser, IUPAC
-// side-channel scan) under AddressSanitizer + UBSan, driven with random and adversarial inputs.
+// side-channel scan; h_pgzip.inc: one gzip member on several threads; h_inflate.inc: gzip / BGZF / bz2 decoders, the bz2
+// 48-bit mark scanner and its re-wrapping of blocks, the BGZF member splitter) under AddressSanitizer + UBSan, driven with
+// random and adversarial inputs.
 // Built and run by tests/test_host_glue.py::test_text_code_under_address_sanitizer (g++; the GPU
 // cannot run sanitizers on this pool).  Every output buffer is allocated at exactly the size
 // the C ABI documents, so an overrun of one byte is an ASan report.
+#include <dlfcn.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <map>
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -20,9 +27,15 @@
 #include "krisp_hip.h"
 
 static thread_local std::string g_last_error;
+typedef unsigned int u32;               // (k_keys.inc's, for the host code that shares the library's spelling)
+typedef unsigned long long u64;
+// stand-ins for the two pinned-memory calls of h_ingest.inc (HIP there): plain heap blocks, so that ASan sees every byte
+static void* host_alloc(size_t bytes) { return malloc(bytes); }
 extern "C" {
+void kr_host_free(void* p) { free(p); }
 #include "../../krisp_amd/csrc/h_text.inc"
 #include "../../krisp_amd/csrc/h_pgzip.inc"
+#include "../../krisp_amd/csrc/h_inflate.inc"      // gzip / BGZF / bz2 decoders and splitters, read_text (round 5)
 }
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -31,6 +44,162 @@ static uint32_t rnd() {
     rng_state ^= rng_state >> 7;
     rng_state ^= rng_state << 17;
     return (uint32_t)(rng_state >> 11);
+}
+
+// ---- h_inflate.inc: files the library did not write.  Sound gzip / BGZF / bz2 files decode to their text on every route
+// (one thread and several; the bz2 block route against the sequential decoder); truncated, bit-flipped, overwritten and
+// MARK-SPOOFING inputs -- a payload that holds the 48-bit bz2 block or end mark by chance, on any bit -- and BGZF headers
+// that lie about their member's length: whatever the verdict, nothing is read or written out of bounds (every input lives
+// in a heap block of exactly its length), a file that decodes "fine" on the block route is what the sequential decoder
+// makes of it, and trailing bytes behind a complete bz2 stream are ignored as Python's bz2 module ignores them.
+typedef int (*bz_compress_t)(char*, unsigned*, char*, unsigned, int, int, int);
+static std::vector<uint8_t> bz_make(bz_compress_t comp, const std::vector<uint8_t>& text, int level) {
+    std::vector<uint8_t> out(text.size() + text.size() / 50 + 1000);
+    unsigned olen = (unsigned)out.size();
+    static char none = 0;
+    if (comp((char*)out.data(), &olen, text.empty() ? &none : (char*)text.data(), (unsigned)text.size(), level, 0, 0) != 0) return {};
+    out.resize(olen);
+    return out;
+}
+static std::vector<uint8_t> gz_make(const std::vector<uint8_t>& text, int level) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return {};
+    std::vector<uint8_t> gz(deflateBound(&zs, (uLong)text.size()) + 64);
+    zs.next_in = (Bytef*)text.data(); zs.avail_in = (uInt)text.size();
+    zs.next_out = gz.data(); zs.avail_out = (uInt)gz.size();
+    deflate(&zs, Z_FINISH);
+    gz.resize(gz.size() - zs.avail_out);
+    deflateEnd(&zs);
+    return gz;
+}
+// BGZF: members of <= 60000 bytes of text, each with the 'B' 'C' extra field naming its length, then the empty end member
+static std::vector<uint8_t> bgzf_make(const std::vector<uint8_t>& text) {
+    std::vector<uint8_t> out;
+    static const uint8_t none = 0;
+    auto member = [&](const uint8_t* p, size_t len) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        std::vector<uint8_t> raw(deflateBound(&zs, (uLong)len) + 64);
+        zs.next_in = (Bytef*)(len ? p : &none); zs.avail_in = (uInt)len;
+        zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
+        deflate(&zs, Z_FINISH);
+        raw.resize(raw.size() - zs.avail_out);
+        deflateEnd(&zs);
+        const uint32_t bsize = (uint32_t)(raw.size() + 25), crc = (uint32_t)crc32(0, len ? p : &none, (uInt)len), isz = (uint32_t)len;
+        const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)bsize, (uint8_t)(bsize >> 8)};
+        out.insert(out.end(), head, head + 18);
+        out.insert(out.end(), raw.begin(), raw.end());
+        for (int k = 0; k < 4; k++) out.push_back((uint8_t)(crc >> (8 * k)));
+        for (int k = 0; k < 4; k++) out.push_back((uint8_t)(isz >> (8 * k)));
+    };
+    for (size_t a = 0; a < text.size(); a += 60000) member(text.data() + a, std::min<size_t>(60000, text.size() - a));
+    member(nullptr, 0);                         // the empty end mark
+    return out;
+}
+static int inflate_fuzz(long* sound, long* damaged, long* agreed) {
+    void* h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+    bz_compress_t comp = h ? (bz_compress_t)dlsym(h, "BZ2_bzBuffToBuffCompress") : nullptr;
+    const bool have_bz = comp && libbz2().ok;
+    auto decode = [&](int kind, const std::vector<uint8_t>& blobv, std::vector<uint8_t>& text, int* rc_seq, std::vector<uint8_t>* seq) {
+        // the input in a block of EXACTLY its size
+        std::unique_ptr<uint8_t[]> blob(new uint8_t[blobv.size() ? blobv.size() : 1]);
+        if (!blobv.empty()) memcpy(blob.get(), blobv.data(), blobv.size());
+        RawBuf out;
+        int64_t members = 0;
+        int used = 0, rc;
+        if (kind == 0) rc = inflate_gzip(blob.get(), blobv.size(), out, &members, &used);
+        else if (kind == 1) {
+            rc = inflate_bgzf(blob.get(), blobv.size(), out, &members, &used);
+            if (rc == 0) rc = inflate_gzip(blob.get(), blobv.size(), out, &members, &used);
+            else if (rc == 1) rc = KR_OK;
+        } else {
+            rc = inflate_bz2(blob.get(), blobv.size(), out, &members);
+            if (seq) {              // the sequential decoder's verdict on the same bytes
+                RawBuf o2;
+                int64_t s2 = 0;
+                *rc_seq = o2.reserve(blobv.size() * 5 + (1 << 16)) ? bunzip_range(blob.get(), blobv.size(), o2, &s2) : KR_ERR_CAPACITY;
+                seq->assign(o2.p, o2.p + (*rc_seq == KR_OK ? o2.len : 0));
+            }
+        }
+        if (rc == KR_OK && out.len > out.cap) return -100;
+        text.assign(out.p, out.p + (rc == KR_OK ? out.len : 0));
+        return rc;
+    };
+    for (int it = 0; it < 36; it++) {
+        const size_t n = it < 3 ? (size_t)it : (it % 3 == 0 ? 150000 + rnd() % 400000 : 100 + rnd() % 90000);
+        std::vector<uint8_t> text(n);
+        for (size_t i = 0; i < n; i++) text[i] = (uint8_t)(i % 61 == 60 ? '\n' : (it % 4 == 3 ? rnd() : "ACGTacgtN"[rnd() % 9]));
+        for (int kind = 0; kind < 3; kind++) {
+            if (kind == 2 && !have_bz) continue;
+            std::vector<uint8_t> blob = kind == 0 ? gz_make(text, 1 + it % 9) : kind == 1 ? bgzf_make(text) : bz_make(comp, text, 1);
+            if (kind == 2 && it % 5 == 4) {         // several streams, as pbzip2 writes them
+                std::vector<uint8_t> t2(text.begin() + n / 2, text.end()), t1(text.begin(), text.begin() + n / 2);
+                blob = bz_make(comp, t1, 1);
+                const std::vector<uint8_t> b2 = bz_make(comp, t2, 2);
+                blob.insert(blob.end(), b2.begin(), b2.end());
+            }
+            if (blob.empty()) return 30;
+            for (const char* threads : {"4", "1"}) {
+                setenv("KRISP_INGEST_THREADS", threads, 1);
+                std::vector<uint8_t> got, seq;
+                int rs = 0;
+                const int rc = decode(kind, blob, got, &rs, kind == 2 ? &seq : nullptr);
+                if (rc != KR_OK || got != text) { printf("sound file of kind %d (%zu bytes of text, threads %s): rc %d\n", kind, n, threads, rc); return 31; }
+                if (kind == 2 && (rs != KR_OK || seq != text)) return 32;
+                (*sound)++;
+            }
+            setenv("KRISP_INGEST_THREADS", "4", 1);
+            for (int dmg = 0; dmg < 14; dmg++) {
+                std::vector<uint8_t> b(blob);
+                const size_t m = b.size();
+                bool tail_only = false;
+                switch (dmg % 7) {
+                case 0: b.resize(rnd() % (m + 1)); break;                                        // truncated anywhere
+                case 1: if (m) b[rnd() % m] ^= (uint8_t)(1u << (rnd() & 7)); break;              // one bit
+                case 2: for (int q = 0; q < 8 && m; q++) b[rnd() % m] = (uint8_t)rnd(); break;   // bytes overwritten
+                case 3: {                                                                         // a spoofed mark inside the payload, on any bit
+                    if (m < 40) break;
+                    const uint64_t mark = (rnd() & 1) ? 0x314159265359ull : 0x177245385090ull;
+                    const size_t bit = (20 + rnd() % (m - 32)) * 8 + (rnd() & 7);
+                    for (int q = 0; q < 48; q++) {
+                        const size_t at = bit + (size_t)q;
+                        const uint8_t msk = (uint8_t)(0x80u >> (at & 7));
+                        if ((mark >> (47 - q)) & 1) b[at >> 3] |= msk; else b[at >> 3] &= (uint8_t)~msk;
+                    }
+                    break;
+                }
+                case 4: {                                                                         // trailing bytes behind the file
+                    const char* tails[] = {"XYZ\n", "\0\0\0", "BZh9garbage-not-a-stream", "BZx"};
+                    const char* t = tails[rnd() % 4];
+                    const size_t tl = t[0] ? strlen(t) : 3;
+                    b.insert(b.end(), (const uint8_t*)t, (const uint8_t*)t + tl);
+                    tail_only = true;
+                    break;
+                }
+                case 5: if (m > 30) { const size_t a = 10 + rnd() % (m - 20); b.erase(b.begin() + a, b.begin() + a + 1 + rnd() % 9); } break;   // bytes missing
+                case 6: if (m > 18) { b[16] = (uint8_t)rnd(); b[17] = (uint8_t)rnd(); } break;   // a BGZF header that lies about its length
+                }
+                std::vector<uint8_t> got, seq;
+                int rs = 0;
+                const int rc = decode(kind, b, got, &rs, kind == 2 ? &seq : nullptr);
+                if (rc == -100) return 33;
+                if (kind == 2) {
+                    // the block route may decline, never disagree: same verdict class and, when both decode, the same text
+                    if ((rc == KR_OK) != (rs == KR_OK) || (rc == KR_OK && got != seq)) {
+                        printf("bz2 damage %d: block route rc %d (%zu bytes), sequential rc %d (%zu bytes)\n", dmg % 7, rc, got.size(), rs, seq.size());
+                        return 34;
+                    }
+                    if (tail_only && (rc != KR_OK || got != text)) { printf("bz2: trailing bytes behind a stream are not ignored (rc %d)\n", rc); return 35; }
+                    (*agreed)++;
+                }
+                (*damaged)++;
+            }
+        }
+    }
+    return 0;
 }
 
 int main() {
@@ -228,6 +397,10 @@ int main() {
             }
         }
     }
-    printf("ASAN_HOST_OK %ld scans %ld renders %ld window renders %ld members on threads %ld refused\n", checks, renders, wrenders, members, refused);
+    long sound = 0, damaged = 0, agreed = 0;
+    const int fr = inflate_fuzz(&sound, &damaged, &agreed);
+    if (fr) { printf("inflate fuzz failed: %d\n", fr); return fr; }
+    printf("ASAN_HOST_OK %ld scans %ld renders %ld window renders %ld members on threads %ld refused; inflate: %ld sound files, "
+           "%ld damaged, %ld bz2 verdicts agreed\n", checks, renders, wrenders, members, refused, sound, damaged, agreed);
     return 0;
 }

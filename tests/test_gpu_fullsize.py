@@ -346,6 +346,7 @@ def test_c4_thirty_two_genomes_on_one_gpu_and_sharded_over_world_eight(tmp_path,
     # (b) world 8: a thread per rank (the library calls release the GIL), every rank its own context on this GPU
     monkeypatch.setenv("KR_PLACE_TRIES", "1")           # (eight contexts at once: no need to try 8 x 8 buffers)
     out, errs, calls = [None] * world, [None] * world, [None] * world
+    costs = [[] for _ in range(world)]
     comm_dir = str(tmp_path / "comm")
 
     class Recorder:
@@ -372,8 +373,11 @@ def test_c4_thirty_two_genomes_on_one_gpu_and_sharded_over_world_eight(tmp_path,
                 res = {}
                 for filt in (False, True):
                     log = []
+                    before = eng.debug_comm()
                     n, nrec = DD.sharded_step(Recorder(eng, log), ids, [f for _, f, _ in shards[rank]], world,
                                               apply_filter=filt)
+                    after = eng.debug_comm()
+                    costs[rank].append({k: after[k] - before[k] for k in ("syncs", "p2p", "collectives")})
                     calls[rank] = log
                     cands = eng.cands().copy()
                     total = eng.records_gather()
@@ -399,6 +403,16 @@ def test_c4_thirty_two_genomes_on_one_gpu_and_sharded_over_world_eight(tmp_path,
     want = ["sort"] * per + ["intersect", "cands_reduce", "cands_bcast", "collect"]
     assert all(c == want for c in calls), calls
     assert "D.sharded_step(eng, ids, flags, world" in inspect.getsource(bench.main)
+    # (d) the exchange of one step is a bounded number of blocking calls (round 5): on rank 0 at world 8
+    # one agreement before the tree (a second one only in the first exchange of a context, when buffers must grow), one
+    # receive + one synchronisation per round of the tree, one agreement before the broadcast it is the root of -- 5 host
+    # synchronisations from the second step on; a rank that only sends synchronises for the two agreements and the
+    # broadcast's header
+    first, second = costs[0]
+    assert second["syncs"] <= 5 and first["syncs"] <= 6, costs[0]
+    assert second["p2p"] == 3 + 7 and second["collectives"] == 2, costs[0]       # (file transport: the broadcast is 7 sends)
+    for r in range(1, world):
+        assert costs[r][1]["syncs"] <= 3 + (r & -r).bit_length() - 1, (r, costs[r])
     print(f"\nconfigs[3]: {len(one[False][0])} / {len(c1)} candidates without / with the filter, {len(one[False][1])} / "
           f"{len(one[True][1])} records; generation {t1 - t0:.0f} s, one GPU {t2 - t1:.0f} s, "
           f"world 8 {time.time() - t2:.0f} s")
