@@ -435,6 +435,14 @@ def main():
         step()
         eng.stage_reset()
         barrier()
+    # the price of one blocking call of the exchange on this box (RCCL communicators: --force-comm at N = 1, any N > 1):
+    # 28 KB = a list of ~1200 candidates (what configs[1]'s filter leaves per rank)
+    comm_probe = None
+    if comm and args.transport == "rccl":
+        try:
+            comm_probe = eng.comm_probe(28 << 10, 50)
+        except _native.KrispHipError as e:
+            comm_probe = {"error": str(e)}
     comm0 = eng.debug_comm() if comm else None
     t0 = time.perf_counter()
     ncand = 0
@@ -506,8 +514,10 @@ def main():
             # profiles/make_traffic.py): per launch of the dominant kernel and per step.  The file names the build it was
             # measured with (hash of the HIP sources): with another build nothing is printed from it.
             traffic, step_roof, traffic_meta = None, None, None
-            tfile = os.path.join(ROOT, "profiles", "traffic_wide.json" if wide else "traffic.json")
-            if os.path.exists(tfile) and not custom and cfg in (1, 2) and world == 1 and gen_8d:
+            # (one PMC file per BASELINE config: traffic.json = configs[1], traffic_c2.json / traffic_c4.json from
+            # tools/profile_config.sh -- their launches differ in size by phase and slice: bytes per STEP there)
+            tfile = os.path.join(ROOT, "profiles", "traffic.json" if cfg == 1 else f"traffic_c{cfg}.json")
+            if os.path.exists(tfile) and not custom and world == 1 and gen_8d:
                 try:
                     from krisp_amd import build as kb
                     tj = json.load(open(tfile))
@@ -518,9 +528,8 @@ def main():
                                                  f"{kb.source_sha16()}: no traffic figures"}
                     else:
                         traffic_meta = meta
-                        if wide:            # (launch sizes differ by phase and slice: bytes and time per STEP there)
-                            tb = tj.get(dom, {}).get("bytes_per_step")
-                            traffic = round(tb / (calib[dom][0] * 1e-3) / 1e9, 1) if tb else None
+                        if cfg != 1:
+                            traffic = None          # (a stage is several kernels there, a kernel serves several stages)
                         else:
                             tb = tj.get(dom, {}).get("bytes_per_launch")
                             traffic = round(tb / (alone_ms * 1e-3) / 1e9, 1) if tb else None
@@ -567,6 +576,7 @@ def main():
             "rccl_ranks": eng.comm_rccl_ranks(),     # (ncclCommCount: 0 = no RCCL communicator in this run)
             # the ONE exchange of a step on rank 0 (kr_debug_comm): blocking calls and host time inside kr_cands_reduce +
             # kr_cands_bcast (the time includes waiting for the slowest rank's sorts: the tree is the step's first meeting)
+            "exchange_call_cost": comm_probe,
             "exchange": None if not comm or world == 1 else {
                 "ms_per_step": round((comm1["exchange_us"] - comm0["exchange_us"]) / args.steps / 1e3, 4),
                 "host_syncs_per_step": (comm1["syncs"] - comm0["syncs"]) / args.steps,

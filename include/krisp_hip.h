@@ -372,6 +372,10 @@ int     kr_debug_isect(kr_ctx*, int64_t* out8);
  * [2] collectives, [3] microseconds inside kr_cands_reduce / kr_cands_bcast, [4] kr_cands_reduce calls, [5] entries of the
  * agreed message size */
 int     kr_debug_comm(kr_ctx*, int64_t* out8);
+/* microseconds per blocking call of the exchange on this box (host clock, RCCL communicator of any world size, every rank
+ * calls it): out3[0] all-reduce of three doubles + synchronisation, [1] a send / receive pair of `bytes` to the rank itself
+ * + synchronisation, [2] a broadcast of `bytes` + synchronisation */
+int     kr_debug_comm_probe(kr_ctx*, size_t bytes, int reps, double* out3);
 /* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
 int64_t kr_debug_budget_left(kr_ctx*);
 int     kr_debug_budget_set(kr_ctx*, int64_t left);

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("kr_debug_copy_which", _c.c_char_p, [_P]),
     ("kr_mem_info", _c.c_int, [_P, _P]),
     ("kr_debug_comm", _c.c_int, [_P, _P]),
+    ("kr_debug_comm_probe", _c.c_int, [_P, _c.c_size_t, _c.c_int, _P]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
     ("kr_render_records", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _c.c_size_t, _P,
                                        _c.c_int, _P, _P, _P, _P]),
@@ -615,6 +616,13 @@ class Engine:
         self._check(self.lib.kr_debug_comm(self.ctx, _ptr(o)), "kr_debug_comm")
         return dict(syncs=int(o[0]), p2p=int(o[1]), collectives=int(o[2]), exchange_us=int(o[3]), reduces=int(o[4]),
                     message_entries=int(o[5]))
+
+    def comm_probe(self, nbytes=64 << 10, reps=50):
+        """microseconds per blocking call of the exchange (kr_debug_comm_probe; RCCL communicators only)"""
+        o = np.zeros(3, dtype=np.float64)
+        self._check(self.lib.kr_debug_comm_probe(self.ctx, nbytes, reps, _ptr(o)), "kr_debug_comm_probe")
+        return dict(allreduce_sync_us=round(float(o[0]), 2), sendrecv_self_sync_us=round(float(o[1]), 2),
+                    bcast_sync_us=round(float(o[2]), 2), message_bytes=int(nbytes))
 
     def copy_which(self):
         """the copy form and grid the latest copy_gbps() found fastest"""

@@ -299,6 +299,23 @@ STREAM_MIN = 1 << 30         # ... and from which the files are read one after t
 
 def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
                                 workers, t0):
+    """find_regions' packed path; a genome set the plan thought would fit and the device then could not hold (the plan
+    is an estimate: candidate lists, slices of a skewed genome, another process on the device) is run again in batches"""
+    from . import _native
+    try:
+        return _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
+                                   workers, t0, None)
+    except _native.KrispHipError as e:
+        if e.code != _native.ERR_CAPACITY or len(files) < 2 or os.environ.get("KRISP_STREAM_BATCH"):
+            raise
+        if verbose:
+            print(f"=> the genome set does not fit the device at once ({e}): in batches", file=sys.stderr)
+    return _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
+                               workers, t0, (len(files) + 1) // 2)
+
+
+def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, verbose, do_filter, quirk_all_fail,
+                        workers, t0, force_batch):
     """find_regions' packed path with the reader on the device: the host threads read and inflate, the main thread
     hands each text to the GPU (parse -> sort) as it arrives.  Same results as the host-parse flow (the device reader
     equals kr_fasta_to_bases byte for byte: tests/test_gpu_kernels.py)."""
@@ -325,7 +342,7 @@ def _find_regions_device_ingest(files, ingroup_files, L, R, k, geo, omit_soft, d
     budget = int(os.environ.get("KRISP_HBM_BUDGET", "0"))       # (bytes; tests and shared devices: kr_create's HBM budget)
     with ThreadPoolExecutor(max_workers=workers) as pool, _native.Engine(device=device, hbm_budget=budget) as eng:
         # a genome set the device cannot hold sorted at once goes through it in batches (the streaming flow above)
-        batch = _plan_batch(eng, len(files), est) if len(files) > 1 else None
+        batch = force_batch or (_plan_batch(eng, len(files), est) if len(files) > 1 else None)
         if batch is not None:
             t1 = time.time()
             eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=max(est, 1))
@@ -1297,7 +1314,14 @@ def filterAlignments(kmerfile, output, ingroup, device=0):
 # ----------------------------------------------------------------------------
 def build_parser():
     p = argparse.ArgumentParser(description="Find diagnostic alignments for a set of fasta files",
-                                prog="krisp", formatter_class=argparse.RawTextHelpFormatter)
+                                prog="krisp", formatter_class=argparse.RawTextHelpFormatter,
+                                epilog="Limits of the GPU path, none of which the reference has (it works on text of any length;\n"
+                                       "kstream.py:617-642) -- each is refused with a message, never answered wrongly:\n"
+                                       "  * a sequence file of 2^32 bases or more (4.29 Gbp; positions are 32 bits on the device);\n"
+                                       "  * amplicons longer than 32 bases (or more than 16 diagnostic bases): conserved flanks of 1 .. 64\n"
+                                       "    bases each, amplicons of at most 256.\n"
+                                       "A genome set that does not fit the GPU's memory sorted at once goes through it in batches\n"
+                                       "(same result; KRISP_STREAM_BATCH=n forces batches of n genomes).")
     p.add_argument("files", nargs="+", type=str, metavar="PATH", help="Fasta file to read. .gz, .bz2")
     p.add_argument("--outgroup", nargs="*", type=str, default=[], metavar="PATH",
                    help="Outgroup Fasta files. To be amplified, but not detected")

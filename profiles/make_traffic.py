@@ -6,7 +6,7 @@ the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exa
 `_step` = the bytes of ALL kernels of one step (the profiled command runs exactly one step: --steps 1 --warmup 0
 --no-stage-timers), less the kernels that are not part of a step (the copy-rate probe of bench.py, the placement
 probes of a context's first sort); `_meta` names the build (hash of the HIP sources) and the round.
-usage: make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [round]"""
+usage: make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [round] [bench arguments]"""
 import collections
 import csv
 import json
@@ -45,8 +45,8 @@ def main():
     from krisp_amd import build as kb
     out["_meta"] = {"source_sha16": kb.source_sha16(), "round": sys.argv[4] if len(sys.argv) > 4 else None,
                     "measured": time.strftime("%Y-%m-%d %H:%M:%S"),
-                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 "
-                               "--no-cpu-baseline --no-stage-timers"}
+                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py " +
+                               (sys.argv[5] + " " if len(sys.argv) > 5 else "") + "--steps 1 --warmup 0 --no-cpu-baseline --no-stage-timers"}
     kern = {}
     for k in sorted(set(tf) | set(tw)):
         if k.startswith(NOT_A_STEP):

@@ -895,3 +895,36 @@ def test_late_genomes_probe_the_candidates_of_the_early_ones(N, K, lanes, n, per
             wnf = K.intersect(want_keys, flags, L, D, R, apply_filter=False)
             assert e.intersect(list(range(n)), flags, apply_filter=False) == len(wnf)
             assert np.array_equal(e.cands()["prefix"], wnf["prefix"]) and e.debug_isect()["splits"] == info["splits"]
+
+
+def test_collect_in_chunks_of_candidates(N, K, monkeypatch):
+    """kr_collect takes the candidates in chunks (a thread, a count and a place per (candidate, genome) pair: 2^28 pairs per
+    chunk, so that neither the 32-bit pair index nor the scratch bounds a call -- ADVICE r4).  KR_COLLECT_PAIRS makes the
+    chunks small: 1, 7 and 1000 pairs per chunk give the records of one chunk, in the same order, also when the record
+    buffer has to grow in the middle, with and without the filter, with key-space slices"""
+    fam = _family(31, 5, 120_000, mu=0.004)
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+    for slices in (None, 1):
+        got = {}
+        for pairs in (None, "1000", "7", "1"):
+            if pairs is None:
+                monkeypatch.delenv("KR_COLLECT_PAIRS", raising=False)
+            else:
+                monkeypatch.setenv("KR_COLLECT_PAIRS", pairs)
+            with N.Engine() as e:
+                if slices is not None:
+                    e.set_option(N.OPT_SLICE_BASES, slices)
+                e.set_params(10, 2, 4, max_bases=max(len(t) for _, _, t in fam))
+                for i, (_, _, t) in enumerate(fam):
+                    e.add(i, t)
+                res = []
+                for filt in (True, False):
+                    n = e.intersect(ids, flags, apply_filter=filt)
+                    assert n > (5 if filt else 1000)
+                    if pairs in ("1", "7") and not filt:
+                        e.load_cands(e.cands()[:300].copy())         # (a chunk per candidate: keep the launch count sane)
+                    res.append(e.collect(ids).tobytes())
+                got[pairs] = res
+        assert got[None] == got["1000"]
+        assert got["7"] == got["1"] and got["7"][0] == got[None][0]

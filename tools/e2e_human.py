@@ -2,7 +2,9 @@
 bases each (1 in / 1 out, k = 31 as 28/1/2) -> read, inflate (one member per file, cut into chunks: csrc/h_pgzip.inc),
 parse on the device, sort in key-space slices, intersect + filter, collect, render.  The genomes differ in `mu` of their
 bases (default 2e-4: ~10^6 diagnostic groups; SURVEY 8(d)'s 0.01 would give 6.5e7 groups = gigabytes of text).
-    python tools/e2e_human.py [length, default 3e9] [mu]            (on the GPU box; writes to stdout)"""
+    python tools/e2e_human.py [length, default 3e9] [mu] [genomes, default 2]            (on the GPU box; writes to stdout)
+With three genomes (2 in / 1 out) the sorted set no longer fits 288 GB: the streaming flow takes them in batches
+(krisp_fasta._find_regions_streaming; round 5)."""
 import os
 import sys
 import tempfile
@@ -18,9 +20,10 @@ from krisp_amd import krisp_fasta as KF  # noqa: E402
 
 length = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
 mu = float(sys.argv[2]) if len(sys.argv) > 2 else 2e-4
+ngen = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 t0 = time.time()
-fam = synth.family(5, 1, 1, length, records=24, mu=mu, snp_every=100_000)
-print(f"2 x {length / 1e9:g} Gbp, mu = {mu:g}: generated in {time.time() - t0:.0f} s", flush=True)
+fam = synth.family(5, ngen - 1, 1, length, records=24, mu=mu, snp_every=100_000)
+print(f"{ngen} x {length / 1e9:g} Gbp, mu = {mu:g}: generated in {time.time() - t0:.0f} s", flush=True)
 
 
 def fasta_gz(path, text, width=80, level=1):
@@ -52,14 +55,14 @@ def fasta_gz(path, text, width=80, level=1):
 
 with tempfile.TemporaryDirectory() as td:
     t1 = time.time()
-    paths, sizes = [], [0, 0]
+    paths, sizes = [], [0] * ngen
 
     def one(i):
         name, ing, text = fam[i]
         p = os.path.join(td, name + ".fa.gz")
         paths.append((i, p))
         sizes[i] = fasta_gz(p, text)
-    th = [threading.Thread(target=one, args=(i,)) for i in range(2)]
+    th = [threading.Thread(target=one, args=(i,)) for i in range(ngen)]
     [x.start() for x in th]
     [x.join() for x in th]
     paths = [p for _, p in sorted(paths)]
@@ -69,9 +72,9 @@ with tempfile.TemporaryDirectory() as td:
     for rep in range(2):
         fasta.LAST_TIMINGS.clear()
         t2 = time.time()
-        groups, stats = KF.find_regions(paths[:1], paths[1:], 28, 2, 31)
+        groups, stats = KF.find_regions(paths[:ngen - 1], paths[ngen - 1:], 28, 2, 31)
         t3 = time.time()
-        csv, align = amplicon.render(groups, [KF.simplename(paths[0])])
+        csv, align = amplicon.render(groups, [KF.simplename(p) for p in paths[:ngen - 1]])
         t4 = time.time()
         tm = list(fasta.LAST_TIMINGS.values())
         mx = lambda key: max((t[key] for t in tm), default=0.0)  # noqa: E731
@@ -80,4 +83,6 @@ with tempfile.TemporaryDirectory() as td:
               f"{t4 - t3:.2f} s | {stats['kmers']:,} k-mers, {len(groups):,} groups, CSV {len(csv) / 1e6:.1f} MB, alignment {len(align) / 1e6:.1f} MB",
               flush=True)
         print("       device part: " + ", ".join(f"{k} {v:.3f}" for k, v in stats.get("stage_s", {}).items()), flush=True)
+        if stats.get("streamed"):
+            print(f"       streamed: batches of {stats['batch']} genome(s), {stats['batches']} batch(es), {stats['passes']} pass(es)", flush=True)
         del groups, csv, align
