@@ -98,7 +98,7 @@ class kstream:
         plan = self.device_plan()
         if (plan is None or plan.get("multi") or plan.get("wide") or plan["strands"] != 0 or plan["layout"] != "lrd"
                 or len(plan["fields"]) != 3 or not plan["sorted"] or plan["allow"] is not None
-                or plan["keepcase"] or plan["expand"]):
+                or plan["keepcase"] or plan["expand"] or self.disallow != {"N", "n"} or self.allow is not None):
             return None
         return plan["geometry"]
 
@@ -110,8 +110,9 @@ class kstream:
         """How the GPU serves this option set, or None (-> the host generator chain; `plan_reason` then says why).
 
         On the device: k <= 32 (one or several: one sort per k, the sorted streams merged); both strands (complements),
-        forward only, or canonicals; omitsoft, mapsoft or neither (lower case kept); disallow == 'Nn' (or an --allow set
-        without N); --allow of plain bases; --expand-iupac; split None, [a], [a, -b] (a, b >= 0); sorted with ANY
+        forward only, or canonicals; omitsoft, mapsoft or neither (lower case kept); any --disallow / --allow set, or none
+        (what they say about A, C, G, T is a base mask on the device, the rest applies to the host's special windows);
+        --expand-iupac; split None, [a], [a, -b] (a, b >= 0); sorted with ANY
         --sort-cols -- GNU sort falls back to the whole line, so a column list is a permutation of the fields followed
         by line order, and the key holds the fields in that order (kr_set_field_order; the krisp_fasta order (first,
         last, middle) keeps its own layout and kernels) -- or unsorted (stream order).  k > 32: the krisp_fasta
@@ -120,9 +121,8 @@ class kstream:
         anything else that the chain would keep -- IUPAC letters, lower case under 'neither', other characters -- runs
         through the reference's chain on the host by itself and joins the sorted stream.
         Not on the device, with the reason in `plan_reason`:
-          * disallow sets other than 'Nn', --allow of letters beyond ACGTN, or an --allow set that both strands do not
-            share (the complement is formed before the filter);
-          * windows with N surviving (also under --expand-iupac: 4^n expansions per window);
+          * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
+            formed before the filters);
           * the column order (last, middle, first) of three non-empty fields whose outer widths differ: it needs two
             different shifts of the same direction, which one key layout does not have;
           * unsorted streams (no --sort) of several k, or of inputs that hold characters beyond ACGTN (their k-mers
@@ -150,19 +150,21 @@ class kstream:
             return self._no_plan("sort must be True or False")
         keepcase = not self.omitsoft and not self.mapsoft
         strands = 0 if self.complements else (2 if self.canonicals else 1)
-        # --allow (kstream.py:696-713) of plain bases = a base mask on the device; letters the 2-bit
-        # alphabet cannot carry in the allowed set (ambiguity codes, '-', ...) stay on the host chain.
-        # Both strands are emitted BEFORE the allow filter: the set must be closed under complement
-        allow_bases = None
+        # --allow / --disallow (kstream.py:696-732).  The device carries windows of plain upper-case ACGT only, so of both
+        # sets only what they say about A, C, G, T decides there: a base mask in the pack kernel (kr_set_allow).  Every
+        # other character -- ambiguity letters, N when nothing drops it, '-', lower case that is kept -- makes its window a
+        # "special" that runs through the reference's own chain on the host (_special_outputs), where both sets apply as
+        # they are (round 5: any disallow set, none at all, --allow of any letters).
+        # Both strands are emitted BEFORE the filters: the surviving bases must be closed under complement, or a window
+        # and its reverse complement would have to be told apart on the device
+        base_ok = set("ACGT")
         if self.allow is not None:
-            if not self.allow <= set("ACGTNacgtn"):
-                return self._no_plan("--allow of letters beyond ACGTN")
-            allow_bases = "".join(sorted(self.allow & set("ACGT")))
-            if strands == 0 and {COMP_MAP[b] for b in allow_bases} != set(allow_bases):
-                return self._no_plan("--allow set not closed under complement while both strands are emitted")
-        n_survives = self.allow is None or "N" in self.allow or (keepcase and "n" in self.allow)
-        if self.disallow != {"N", "n"} and not (self.disallow is None and not n_survives):
-            return self._no_plan("windows holding N must be dropped (disallow 'Nn' or an --allow set without N); other disallow sets are not planned")
+            base_ok &= self.allow
+        if self.disallow is not None:
+            base_ok -= self.disallow
+        allow_bases = None if base_ok == set("ACGT") else "".join(sorted(base_ok))
+        if strands == 0 and {COMP_MAP[b] for b in base_ok} != base_ok:
+            return self._no_plan("the bases --allow / --disallow leave are not closed under complement while both strands are emitted")
         # fields of the output line (kstream.py:805-832)
         if self.split is None:
             fields = [k]
@@ -223,31 +225,72 @@ class kstream:
         # expansion is the handful of combinations of a window's other ambiguity letters)
         return dict(common, layout=layout, order=order, geometry=geometry, sorted=True)
 
+    def _char_tables(self, plan):
+        """(plain, hard, soft, raiser) by byte value.  plain: what the device carries (A C G T; a c g t too under
+        mapsoft).  hard: a character that drops its window BEFORE anything else looks at it -- the record boundary,
+        lower case under omitsoft (the soft-mask step comes first).  soft: a character the filters drop -- after the
+        soft-mask mapping it is in --disallow or outside --allow; with both strands emitted (the complements are formed
+        BEFORE the filters) only when its complement is dropped too.  raiser: with both strands emitted, a character
+        outside COMP_MAP makes the complement step raise KeyError (kstream.py:658) whatever the filters would have said
+        about its window."""
+        import numpy as np
+        plain = np.zeros(256, dtype=bool)
+        plain[list(b"ACGT")] = True
+        if self.mapsoft:
+            plain[list(b"acgt")] = True
+        hard = np.zeros(256, dtype=bool)
+        soft = np.zeros(256, dtype=bool)
+        raiser = np.zeros(256, dtype=bool)
+        hard[10] = True
+
+        def bad(ch):
+            return (self.disallow is not None and ch in self.disallow) or (self.allow is not None and ch not in self.allow)
+        for c in range(256):
+            ch = chr(c)
+            if c == 10:
+                continue
+            if self.omitsoft and ch.islower():
+                hard[c] = True
+                continue
+            m = ch.upper() if self.mapsoft else ch
+            if len(m) != 1:
+                continue
+            if plan["strands"] == 0:
+                if m in COMP_MAP:
+                    soft[c] = bad(m) and bad(COMP_MAP[m])
+                else:
+                    raiser[c] = True
+            else:
+                soft[c] = bad(m)
+        return plain, hard, soft, raiser
+
+    def _has_specials(self, bases, plan):
+        """does any character call for the host's special windows?  (in pieces: no second copy of a genome)"""
+        plain, hard, soft, _ = self._char_tables(plan)
+        either = plain | hard | soft
+        step = 1 << 26
+        return any(not either[bases[a:a + step]].all() for a in range(0, len(bases), step))
+
     def _special_outputs(self, bases, plan):
-        """The k-mers of the windows the device does not carry but the chain may keep, as the reference's own chain
-        makes them (window by window, stream order: the first KeyError is the reference's): windows holding a character
-        outside ACGT -- outside ACGTacgt under mapsoft -- and none that drops the window for sure (N / n, a record
-        boundary, lower case under omitsoft).  One vectorised pass finds them; Python only runs on those windows."""
+        """The k-mers of the windows the device does not carry but the chain may keep -- or raise on --, as the reference's
+        own chain makes them (window by window, stream order: the first KeyError is the reference's): windows without a
+        character that drops them at once, holding a raiser, or a character that is not plain and none the filters drop
+        (_char_tables).  One vectorised pass finds them; Python only runs on those windows."""
         import numpy as np
         k = plan["k"]
         n = len(bases)
         if n < k:
             return []
-        plain = np.zeros(256, dtype=bool)
-        plain[list(b"ACGT")] = True
-        if self.mapsoft:
-            plain[list(b"acgt")] = True
-        skip = np.zeros(256, dtype=bool)
-        skip[10] = True                                   # record boundary
-        skip[list(b"Nn")] = True                          # (the plan made sure both are dropped)
-        if self.omitsoft:
-            skip[[c for c in range(256) if chr(c).islower()]] = True
-        isp = (~plain[bases]) & (~skip[bases])
+        plain, hard, soft, raiser = self._char_tables(plan)
+        isp = (~plain[bases]) & (~hard[bases]) & (~soft[bases])
         if not isp.any():
             return []
-        cs = np.concatenate([[0], np.cumsum(isp, dtype=np.int64)])
-        ck = np.concatenate([[0], np.cumsum(skip[bases], dtype=np.int64)])
-        starts = np.flatnonzero((cs[k:] - cs[:-k] > 0) & (ck[k:] - ck[:-k] == 0))
+
+        def windows(flag):
+            c = np.concatenate([[0], np.cumsum(flag, dtype=np.int64)])
+            return c[k:] - c[:-k]
+        nh, nsft, nsp, nr = windows(hard[bases]), windows(soft[bases]), windows(isp), windows(raiser[bases])
+        starts = np.flatnonzero((nh == 0) & (((nsp > 0) & (nsft == 0)) | (nr > 0)))
         text = bases.tobytes().decode("latin-1")
         return list(self._chain(text[i:i + k] for i in starts.tolist()))
 
@@ -258,17 +301,20 @@ class kstream:
         from . import _native
         L, D, R = plan["geometry"]
         fields, order = plan["fields"], plan["order"]
+        # (the krisp_fasta combination proper -- disallow "Nn", no --allow beyond plain bases and N -- has its own side
+        # channel for IUPAC windows, kr_scan_special; every other option set finds its special windows from the tables)
         krisp_combo = (plan["strands"] == 0 and plan["layout"] == "lrd" and len(fields) == 3 and plan["sorted"]
-                       and not plan["keepcase"] and not plan["expand"])
+                       and not plan["keepcase"] and not plan["expand"] and self.disallow == {"N", "n"}
+                       and (self.allow is None or self.allow <= set("ACGTNacgtn")))
         allow = plan.get("allow")
         if krisp_combo:
             bases, rna, windows = fasta.ingest(sequences, plan["k"], self.omitsoft)    # (KeyError as the reference)
             # (--allow of plain bases drops every k-mer that holds an ambiguity letter)
-            special = [] if allow is not None else list(windows)
+            special = [] if self.allow is not None else list(windows)
         else:
             bases, rna, nspecial = fasta.load_any(sequences)
             special = []
-            if nspecial or plan["keepcase"]:
+            if nspecial or plan["keepcase"] or self._has_specials(bases, plan):
                 if not plan["sorted"]:
                     self.plan_reason = "unsorted stream of an input with characters beyond ACGTN: its host k-mers would have to be placed by position"
                     return None
@@ -353,7 +399,8 @@ class kstream:
         if got is None:
             return None
         keys, rna, special = got
-        if plan["layout"] == "lrd" and len(plan["fields"]) == 3 and not plan["keepcase"] and not plan["expand"] and plan["strands"] == 0 and plan["sorted"]:
+        if (plan["layout"] == "lrd" and len(plan["fields"]) == 3 and not plan["keepcase"] and not plan["expand"] and plan["strands"] == 0
+                and plan["sorted"] and self.disallow == {"N", "n"} and (self.allow is None or self.allow <= set("ACGTNacgtn"))):
             L, D, R = plan["geometry"]
             blocks = codec.merged_line_blocks(keys, [codec.split_window(w, L, D, R) for w in special], L, D, R, rna=rna,
                                               chunk=_WRITE_CHUNK)

@@ -788,6 +788,19 @@ def test_kstream_round_4_routes_equal_the_host_chain(seed, tmp_path):
         kw.update(rng.choice([dict(mapsoft=True), dict(omitsoft=True), {}]))
         if rng.random() < 0.4:
             kw["expandiupac"] = True
+        # round 5: any --disallow set or none, --allow of any letters (what they say about A C G T is the device's base
+        # mask; everything else applies to the host's special windows) -- not with --expand-iupac and N surviving on
+        # long N runs (4^n expansions per window, in the reference too)
+        if trial >= 3:
+            dis = rng.choice(["N", None, "RrNn", "NnAT", "nY", "NnCGcg", "X-"])
+            if dis is None and kw.get("expandiupac"):
+                dis = "N"
+            if dis is None:
+                kw.pop("disallow")
+            else:
+                kw["disallow"] = dis
+            if rng.random() < 0.4:
+                kw["allow"] = rng.choice(["ACGTacgt", "ACGTRYry", "ATat", "ACGTNn", "ACGT", "CGNRY"])
         if split is not None:
             kw["split"] = split
         if cols is not None:
