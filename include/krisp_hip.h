@@ -105,9 +105,9 @@ int kr_set_allow(kr_ctx*, unsigned base_mask);
  * the window is cut into fields of widths[0..2] bases in line order (kstream.py:805-832; an empty field has width 0)
  * and the key holds them in the order order[0], order[1], order[2] (a permutation of 0 1 2), so that the unsigned
  * order of the keys is the order of that column list.  After kr_set_params(k, 0, 0, ...) with k = the sum of the
- * widths (the window as ONE field), before the first upload.  A layout moves every field by one shift; it takes
- * the orders whose fields need at most one distinct left and one distinct right shift (all but 2 1 0 with
- * widths[0] != widths[2] and three non-empty fields: KR_ERR_PARAM, the caller sorts those on the host).  Such a
+ * widths (the window as ONE field), before the first upload.  A layout moves every field by one shift, at most one
+ * distinct left and one distinct right shift; the one order that needs two of a direction (2 1 0 with widths[0] !=
+ * widths[2]) is served by rotating the window by a field boundary first (round 5): every permutation is taken.  Such a
  * context sorts and returns keys (kr_genome_sort, kr_genome_fetch_keys); kr_intersect and kr_collect -- whose
  * prefix is the krisp_fasta layout's -- refuse it. */
 int kr_set_field_order(kr_ctx*, const int widths[3], const int order[3]);
@@ -143,6 +143,13 @@ int64_t kr_cands_load(kr_ctx*, const kr_cand* cands, size_t n);
 /* candidates := candidates INTERSECT other (sorted, unique), masks OR-ed;
  * other == NULL / n == 0 with apply_filter just filters.  Returns the new count. */
 int64_t kr_cands_merge(kr_ctx*, const kr_cand* other, size_t n, int have_other, int apply_filter);
+/* candidates := those whose (left,right) prefix EVERY listed (sorted) genome holds, the genomes' diagnostic bases OR-ed into
+ * the masks of their side (is_ingroup), the diagnostic filter applied when asked for -- what kr_intersect over these genomes
+ * followed by kr_cands_merge would leave, without the genomes' own candidate list in between (for genomes of one side only
+ * that list is every prefix they hold).  One step of the reference's merge tree (intersectAmplicons.py:256-307: a merged
+ * file against the next genome's file) on candidate lists; the streaming flow of genome sets beyond the GPU's memory uses it
+ * for every batch after the first.  Returns the count. */
+int64_t kr_cands_probe(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup, int apply_filter);
 
 /* ---- multi-GPU: one process (one context) per GPU, genomes sharded over the ranks.  Sort and
  * local intersect need no communication; the ONE exchange step is a binary-tree reduction of the

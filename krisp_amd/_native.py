@@ -64,6 +64,7 @@ SYMBOLS = [
     ("kr_cands_fetch", _c.c_int64, [_P, _P, _c.c_size_t]),
     ("kr_cands_load", _c.c_int64, [_P, _P, _c.c_size_t]),
     ("kr_cands_merge", _c.c_int64, [_P, _P, _c.c_size_t, _c.c_int, _c.c_int]),
+    ("kr_cands_probe", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_comm_unique_id", _c.c_int, [_P]),
     ("kr_comm_init", _c.c_int, [_P, _c.c_int, _c.c_int, _P]),
     ("kr_comm_init_dir", _c.c_int, [_P, _c.c_int, _c.c_int, _c.c_char_p]),
@@ -465,6 +466,13 @@ class Engine:
         return self._check(self.lib.kr_cands_merge(self.ctx, _ptr(other) if len(other) else None,
                                                    len(other), 1, 1 if apply_filter else 0),
                            "kr_cands_merge")
+
+    def probe_cands(self, gids, is_ingroup, apply_filter=True):
+        """candidates := those every listed genome holds, masks OR-ed by side, filter (kr_cands_probe)"""
+        ids = np.asarray(gids, dtype=np.int32)
+        flags = np.asarray([1 if f else 0 for f in is_ingroup], dtype=np.uint8)
+        return self._check(self.lib.kr_cands_probe(self.ctx, _ptr(ids), len(ids), _ptr(flags), 1 if apply_filter else 0),
+                           "kr_cands_probe")
 
     def collect(self, gids, fetch=True):
         ids = np.asarray(gids, dtype=np.int32)

@@ -66,19 +66,30 @@ def keys_to_fields_bytes(keys, fields, rna=False):
 
 
 def field_layout_ok(widths, order):
-    """can a key hold the window's fields (widths, line order) in `order` by moving each field with ONE shift --
-    at most one distinct left and one distinct right shift (kr_set_field_order, include/krisp_hip.h)?"""
-    src, at = [], 0
+    """can a key hold the window's fields (widths, line order) in `order`?  kr_set_field_order moves each field with ONE
+    shift -- at most one distinct left and one distinct right shift -- after an optional rotation of the window by a field
+    boundary: every permutation of up to three fields qualifies (round 5; the rotation serves (last, middle, first) with
+    outer fields of different widths).  Kept as the statement of that rule, checked against the library by the tests."""
+    k = sum(widths)
+    src0, at = [], 0
     for w in widths:
-        src.append(at)
+        src0.append(at)
         at += w
     dst, at = {}, 0
     for f in order:
         dst[f] = at
         at += widths[f]
-    left = {src[f] - dst[f] for f in range(len(widths)) if widths[f] and dst[f] < src[f]}
-    right = {dst[f] - src[f] for f in range(len(widths)) if widths[f] and dst[f] > src[f]}
-    return len(left) <= 1 and len(right) <= 1
+    for r in [0] + src0[1:]:
+        if r >= k > 0:
+            continue
+        src = [(s - r) % k if k else 0 for s in src0]
+        if any(widths[f] and src[f] + widths[f] > k for f in range(len(widths))):
+            continue
+        left = {src[f] - dst[f] for f in range(len(widths)) if widths[f] and dst[f] < src[f]}
+        right = {dst[f] - src[f] for f in range(len(widths)) if widths[f] and dst[f] > src[f]}
+        if len(left) <= 1 and len(right) <= 1:
+            return True
+    return False
 
 
 def keys_to_ordered_fields_bytes(keys, fields, order, rna=False):

@@ -476,10 +476,10 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
                             max_bases):
     """find_regions for a genome set that does not fit the GPU at once (the reference has no such limit: it sorts in
     external memory, kstream.py:108-119, and merges files pairwise, intersectAmplicons.py:232-310).  The genomes go
-    through the device in batches of `batch`: sort the batch, intersect it (with the diagnostic filter: the predicate
-    is monotone, so a batch may prune with its partial masks -- in and out genomes are interleaved so that every batch
-    holds both), merge the batch's candidates into the running set (list n list, masks OR-ed: kr_cands_merge), collect
-    the batch's records of the running candidates (a superset of the final ones) and free the batch.  The records of
+    through the device in batches of `batch`: sort the batch; the first batch is intersected (with the diagnostic filter:
+    the predicate is monotone, so partial masks may prune -- in and out genomes are interleaved so that the first batch
+    holds both), every later batch looks the running candidates up in its genomes (kr_cands_probe: presence, masks OR-ed,
+    filter); collect the batch's records of the running candidates (a superset of the final ones) and free the batch.  The records of
     the final candidates are what remains of those; only when the running set was too large to collect from (no
     outgroup, no filter: every conserved pair is a candidate) or IUPAC windows touch groups whose ACGT members must be
     looked up, a second pass sorts every batch again and collects then.  Same records, same order, same text as the
@@ -565,9 +565,14 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
 
     def pass1(ids_b):
         bflags = [flags[g] for g in ids_b]
-        eng.intersect(ids_b, bflags, apply_filter=apply_f)
-        if running[0] is not None:
-            eng.merge_cands(running[0], apply_filter=apply_f)
+        if running[0] is None:
+            eng.intersect(ids_b, bflags, apply_filter=apply_f)
+        else:
+            # (a later batch looks the running candidates up in its genomes -- kr_cands_probe: presence in every genome,
+            # their diagnostic bases into the masks, the filter -- instead of being intersected whole: the candidate list
+            # of a batch that holds one side only is every prefix of its genomes, 24 bytes each)
+            eng.load_cands(running[0])
+            eng.probe_cands(ids_b, bflags, apply_filter=apply_f)
         running[0] = eng.cands().copy()
         if verbose:
             for g in ids_b:

@@ -123,8 +123,6 @@ class kstream:
         Not on the device, with the reason in `plan_reason`:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
             formed before the filters);
-          * the column order (last, middle, first) of three non-empty fields whose outer widths differ: it needs two
-            different shifts of the same direction, which one key layout does not have;
           * unsorted streams (no --sort) of several k, or of inputs that hold characters beyond ACGTN (their k-mers
             would have to be placed by position, not by value), or with --expand-iupac / kept lower case;
           * k > 32 outside the krisp_fasta combination, flanks > 64, k > 256;
@@ -220,7 +218,7 @@ class kstream:
             layout, geometry = "custom", (k, 0, 0)
             order = live + [c for c in range(len(fields)) if c not in live]
             if not codec.field_layout_ok(fields, order):
-                return self._no_plan("column order (last, middle, first) of three fields with different outer widths: two different shifts, no key layout")
+                return self._no_plan("no key layout holds this column order")      # (none known: every permutation of three fields has one)
         # (--expand-iupac: windows holding N are dropped before the expansion -- the disallow / allow test above --, so an
         # expansion is the handful of combinations of a window's other ambiguity letters)
         return dict(common, layout=layout, order=order, geometry=geometry, sorted=True)

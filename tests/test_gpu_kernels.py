@@ -928,3 +928,45 @@ def test_collect_in_chunks_of_candidates(N, K, monkeypatch):
                 got[pairs] = res
         assert got[None] == got["1000"]
         assert got["7"] == got["1"] and got["7"][0] == got[None][0]
+
+
+@pytest.mark.parametrize("slices", [None, 1, 2])
+def test_probe_of_a_candidate_list_equals_the_intersection(N, K, slices):
+    """kr_cands_probe (round 5): the candidates of the first m genomes looked up in the others -- presence in every genome,
+    their diagnostic bases into the masks of their side, the filter -- are the candidates of the intersection over all of
+    them, with and without the filter, for every split of 7 genomes (the later ones of ONE side only, too), with key-space
+    slices; against the packed-key oracle."""
+    L, D, R = 11, 2, 5
+    fam = _family(77, 7, 90_000, mu=0.003)
+    flags = [f for _, f, _ in fam]
+    want_keys = [K.sorted_keys(t.tobytes(), L, D, R) for _, _, t in fam]
+    ids = list(range(len(fam)))
+    with N.Engine() as e:
+        if slices is not None:
+            e.set_option(N.OPT_SLICE_BASES, slices)
+        e.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        for i, (_, _, t) in enumerate(fam):
+            e.add(i, t)
+        for filt in (True, False):
+            want = K.intersect(want_keys, flags, L, D, R, apply_filter=filt)
+            assert len(want) > (3 if filt else 500)
+            for order in (ids, [0, 6, 1, 2, 3, 4, 5], [3, 4, 5, 6, 0, 1, 2]):         # (the last: all outgroup first, ingroup by probe)
+                for m in (1, 2, 4, 6):
+                    head, tail = order[:m], order[m:]
+                    e.intersect(head, [flags[g] for g in head], apply_filter=filt)
+                    n = e.probe_cands(tail, [flags[g] for g in tail], apply_filter=filt)
+                    got = e.cands()
+                    assert n == len(want) == len(got), (filt, order, m)
+                    for f in ("prefix", "in_mask", "out_mask"):
+                        assert np.array_equal(got[f], want[f]), (filt, order, m, f)
+        # a candidate list that came from somewhere else (kr_cands_load), genomes in two calls
+        want = K.intersect(want_keys, flags, L, D, R, apply_filter=False)
+        loaded = want.copy()
+        loaded["in_mask"] = 0
+        loaded["out_mask"] = 0
+        e.load_cands(loaded)
+        e.probe_cands(ids[:3], flags[:3], apply_filter=False)
+        e.probe_cands(ids[3:], flags[3:], apply_filter=False)
+        got = e.cands()
+        for f in ("prefix", "in_mask", "out_mask"):
+            assert np.array_equal(got[f], want[f]), f
