@@ -970,3 +970,60 @@ def test_probe_of_a_candidate_list_equals_the_intersection(N, K, slices):
         got = e.cands()
         for f in ("prefix", "in_mask", "out_mask"):
             assert np.array_equal(got[f], want[f]), f
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_of_empty_and_uneven_candidate_lists(N, K, world, tmp_path):
+    """the exchange's message is never shorter than its header: every rank without a single candidate (the agreed message
+    size is 0 entries), one rank with none among ranks with some, lists of very different lengths -- ranks as threads
+    over the file transport; what comes back is the intersection (empty, empty, the common part) with the masks OR-ed,
+    on every rank after the broadcast, and the record gather of nothing is nothing"""
+    import threading
+    L, D, R = 9, 1, 3
+    rng = np.random.default_rng(3)
+    pool = np.sort(rng.choice(1 << 24, size=5000, replace=False).astype(np.uint64)) << np.uint64(64 - 2 * (L + R))
+
+    def lists(case, rank):
+        c = np.zeros(0, dtype=N.CAND)
+        if case == "all_empty":
+            return c
+        if case == "one_empty" and rank == world - 1:
+            return c
+        take = pool[:: rank + 1] if case == "uneven" else pool[:200]
+        c = np.zeros(len(take), dtype=N.CAND)
+        c["prefix"] = take
+        c["in_mask"] = 1 << rank
+        c["out_mask"] = 16 << rank
+        return c
+    for case in ("all_empty", "one_empty", "uneven"):
+        res, errs = [None] * world, [None] * world
+
+        def work(rank):
+            try:
+                with N.Engine() as e:
+                    e.comm_init_dir(rank, world, str(tmp_path / f"comm_{case}"))
+                    e.set_params(L, D, R, max_bases=1000)
+                    e.load_cands(lists(case, rank))
+                    n = e.cands_reduce(apply_filter=False)
+                    nb = e.cands_bcast()
+                    got = e.cands().copy()
+                    e.lib.kr_collect(e.ctx, None, 0)
+                    tot = e.records_gather()
+                    res[rank] = (n, nb, got, tot)
+                    e.comm_barrier()
+            except BaseException as ex:  # noqa: BLE001
+                errs[rank] = ex
+        ts = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+        assert not any(t.is_alive() for t in ts), (case, res)
+        assert errs == [None] * world, (case, errs)
+        want = pool[:0] if case != "uneven" else pool[:: int(np.lcm.reduce(np.arange(1, world + 1)))]
+        for r in range(world):
+            n, nb, got, tot = res[r]
+            assert nb == len(want) and tot == 0 and (r != 0 or n == len(want)), (case, r, n, nb)
+            assert np.array_equal(got["prefix"], want)
+            if len(want):
+                assert np.all(got["in_mask"] == (1 << world) - 1) and np.all(got["out_mask"] == 16 * ((1 << world) - 1))
