@@ -375,6 +375,10 @@ const char* kr_debug_copy_which(kr_ctx*);
  * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
  * now; out[6..7] = 0 */
 int     kr_debug_isect(kr_ctx*, int64_t* out8);
+/* the latest placement search of the pass-1 output buffers: out8[0] candidates probed, [1] buffers handed to the sort lanes,
+ * [2..5] probe milliseconds of the four fastest candidates, [6] the median, [7] the slowest (bench.py prints them: which
+ * placement class a line ran in) */
+int     kr_debug_place(kr_ctx*, double* out8);
 /* what the multi-GPU exchange has cost this context so far: out[0] host synchronisations, [1] point-to-point calls,
  * [2] collectives, [3] microseconds inside kr_cands_reduce / kr_cands_bcast, [4] kr_cands_reduce calls, [5] entries of the
  * agreed message size */

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("kr_debug_copy_which", _c.c_char_p, [_P]),
     ("kr_mem_info", _c.c_int, [_P, _P]),
     ("kr_debug_comm", _c.c_int, [_P, _P]),
+    ("kr_debug_place", _c.c_int, [_P, _P]),
     ("kr_debug_comm_probe", _c.c_int, [_P, _c.c_size_t, _c.c_int, _P]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
     ("kr_render_records", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _c.c_size_t, _P,
@@ -624,6 +625,13 @@ class Engine:
         self._check(self.lib.kr_debug_comm(self.ctx, _ptr(o)), "kr_debug_comm")
         return dict(syncs=int(o[0]), p2p=int(o[1]), collectives=int(o[2]), exchange_us=int(o[3]), reduces=int(o[4]),
                     message_entries=int(o[5]))
+
+    def debug_place(self):
+        """the latest placement search of the pass-1 output buffers (kr_debug_place)"""
+        o = np.zeros(8, dtype=np.float64)
+        self._check(self.lib.kr_debug_place(self.ctx, _ptr(o)), "kr_debug_place")
+        return dict(candidates=int(o[0]), taken=int(o[1]), fastest_ms=[round(float(x), 4) for x in o[2:6]],
+                    median_ms=round(float(o[6]), 4), slowest_ms=round(float(o[7]), 4))
 
     def comm_probe(self, nbytes=64 << 10, reps=50):
         """microseconds per blocking call of the exchange (kr_debug_comm_probe; RCCL communicators only)"""
