@@ -183,8 +183,6 @@ class kstream:
         if self.sort is False:
             if k > 32:
                 return self._no_plan("k > 32 without --sort")
-            if keepcase or self.expandiupac:
-                return self._no_plan("unsorted stream with kept lower case / --expand-iupac: host k-mers would have to be placed by position")
             # stream order: the window as it is, cut into its fields
             return dict(common, layout="ldr", order=list(range(len(fields))), geometry=(k, 0, 0), sorted=False)
         # effective order of the fields: listed columns, then line order
@@ -269,7 +267,7 @@ class kstream:
         step = 1 << 26
         return any(not either[bases[a:a + step]].all() for a in range(0, len(bases), step))
 
-    def _special_outputs(self, bases, plan):
+    def _special_outputs(self, bases, plan, by_window=False):
         """The k-mers of the windows the device does not carry but the chain may keep -- or raise on --, as the reference's
         own chain makes them (window by window, stream order: the first KeyError is the reference's): windows without a
         character that drops them at once, holding a raiser, or a character that is not plain and none the filters drop
@@ -290,7 +288,25 @@ class kstream:
         nh, nsft, nsp, nr = windows(hard[bases]), windows(soft[bases]), windows(isp), windows(raiser[bases])
         starts = np.flatnonzero((nh == 0) & (((nsp > 0) & (nsft == 0)) | (nr > 0)))
         text = bases.tobytes().decode("latin-1")
+        if by_window:
+            # (unsorted streams: every window's k-mers with its start, to be put between the device's by position)
+            return [(i, list(self._chain(iter([text[i:i + k]])))) for i in starts.tolist()]
         return list(self._chain(text[i:i + k] for i in starts.tolist()))
+
+    def _device_window_starts(self, bases, plan):
+        """starts of the windows the device emits k-mers for, ascending: k characters that are all plain (_char_tables) and,
+        after the soft-mask mapping, bases the --allow / --disallow mask leaves"""
+        import numpy as np
+        k = plan["k"]
+        plain = self._char_tables(plan)[0].copy()
+        if plan["allow"] is not None:
+            for ch in "ACGTacgt":
+                if ch.upper() not in plan["allow"]:
+                    plain[ord(ch)] = False
+        if len(bases) < k:
+            return np.zeros(0, dtype=np.int64)
+        c = np.concatenate([[0], np.cumsum(~plain[bases], dtype=np.int64)])
+        return np.flatnonzero(c[k:] - c[:-k] == 0)
 
     def _device_keys(self, sequences, plan):
         """-> (sorted keys in the plan's field order, is_rna, host k-mers as window strings) or None when only the host
@@ -313,10 +329,8 @@ class kstream:
             bases, rna, nspecial = fasta.load_any(sequences)
             special = []
             if nspecial or plan["keepcase"] or self._has_specials(bases, plan):
-                if not plan["sorted"]:
-                    self.plan_reason = "unsorted stream of an input with characters beyond ACGTN: its host k-mers would have to be placed by position"
-                    return None
-                special = self._special_outputs(bases, plan)
+                # (unsorted: the host's k-mers are put between the device's by the position of their window, round 5)
+                special = self._special_outputs(bases, plan, by_window=not plan["sorted"])
         with _native.Engine(device=self.device) as eng:
             # (lower case kept: the device takes the windows without any, as under omitsoft; the others are `special`)
             eng.set_params(L, D, R, omit_soft=self.omitsoft or plan["keepcase"], max_bases=len(bases))
@@ -337,6 +351,9 @@ class kstream:
             else:
                 eng.upload(0, bases)
                 keys = eng.keys_in_order(0, len(bases))
+        if not plan["sorted"]:
+            # stream order: (keys, rna, [(window start, its k-mers)], starts of the device's windows) -- _device_blocks interleaves
+            return keys, rna, special, (self._device_window_starts(bases, plan) if special else None)
         # host k-mers of plain ACGT (expansions of IUPAC letters) are keys like the device's
         if special and not krisp_combo:
             isplain = [not s.strip("ACGT") for s in special]
@@ -344,7 +361,7 @@ class kstream:
             if len(pk):
                 keys = np.sort(np.concatenate([keys, pk]), kind="stable")
             special = [s for s, p in zip(special, isplain) if not p]
-        return keys, rna, special
+        return keys, rna, special, None
 
     def _device_blocks(self, sequences, plan):
         """-> (iterator of byte blocks of the output, line count) or None"""
@@ -396,7 +413,33 @@ class kstream:
         got = self._device_keys(sequences, plan)
         if got is None:
             return None
-        keys, rna, special = got
+        keys, rna, special, dev_starts = got
+        if not plan["sorted"] and special:
+            import numpy as np
+            # the device's k-mers in stream order (per window: the window, then its reverse complement under --complements)
+            # with the host's special windows' k-mers put in by the position of their window
+            per = 2 if plan["strands"] == 0 else 1
+            assert len(keys) == per * len(dev_starts), (len(keys), len(dev_starts))
+            fields = plan["fields"]
+            width = plan["k"] + len(fields)                     # bytes of a device line, newline included
+
+            def blocks():
+                done = 0                                        # device windows written so far
+                for start, kmers in special:
+                    upto = int(np.searchsorted(dev_starts, start))
+                    for a in range(done, upto, _WRITE_CHUNK):
+                        b = min(upto, a + _WRITE_CHUNK)
+                        yield codec.keys_to_fields_bytes(keys[per * a:per * b], fields, rna)
+                    done = upto
+                    lines = [self._split_one(x) if self.split is not None else x for x in kmers]
+                    if rna:
+                        lines = [x.replace("T", "U").replace("t", "u") for x in lines]
+                    if lines:
+                        yield ("\n".join(lines) + "\n").encode("latin-1")
+                for a in range(done, len(dev_starts), _WRITE_CHUNK):
+                    b = min(len(dev_starts), a + _WRITE_CHUNK)
+                    yield codec.keys_to_fields_bytes(keys[per * a:per * b], fields, rna)
+            return blocks(), int(len(keys)) + sum(len(km) for _, km in special)
         if (plan["layout"] == "lrd" and len(plan["fields"]) == 3 and not plan["keepcase"] and not plan["expand"] and plan["strands"] == 0
                 and plan["sorted"] and self.disallow == {"N", "n"} and (self.allow is None or self.allow <= set("ACGTNacgtn"))):
             L, D, R = plan["geometry"]

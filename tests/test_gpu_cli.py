@@ -1020,3 +1020,58 @@ def test_streaming_flow_equals_the_in_core_flow(case, tmp_path, monkeypatch):
     got, stats = KF.find_regions(ing, outg, L, R, k)
     assert stats["streamed"] and 1 <= stats["batch"] < 6, stats
     assert _render_groups(got, labels) == want_text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_kstream_unsorted_streams_with_special_windows(seed, tmp_path):
+    """round 5: stream order (no --sort) of inputs with IUPAC letters, N, kept lower case, stray characters, RNA -- the device
+    emits the k-mers of the plain windows in position order (kr_genome_keys_in_order), the host's special windows run through
+    the reference's chain and are put in by the position of their window; with --expand-iupac, any --disallow / --allow,
+    every strand mode and split.  Line for line the plain generator chain (pinned to the reference by its vectors, among
+    them host_unsorted_iupac / host_unsorted_keepcase / expand_unsorted_comp), write() and exceptions included."""
+    import random
+    from krisp_amd.kstream import kstream
+    rng = random.Random(6600 + seed)
+    alphabet = "ACGT" * 8 + "acgt" * 2 + "NnRYKMry" + ("X-" if seed % 5 == 4 else "")
+    recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 1500))) for _ in range(rng.randint(1, 4))]
+    text = "".join(f">r{i}\n{r}\n" for i, r in enumerate(recs))
+    if seed % 4 == 3:
+        text = text.replace("T", "U").replace("t", "u")
+    src = str(tmp_path / "u.fa")
+    open(src, "w").write(text)
+    ran = 0
+    for trial in range(6):
+        k = rng.choice([3, 6, 11, 20, 31])
+        kw = dict(kmers=k, sort=False)
+        kw.update(rng.choice([dict(complements=True), dict(canonicals=True), {}]))
+        kw.update(rng.choice([dict(mapsoft=True), dict(omitsoft=True), {}]))
+        dis = rng.choice(["Nn", "Nn", "N", None, "RrNn", "X-Nn"])
+        if rng.random() < 0.4:
+            kw["expandiupac"] = True
+            dis = dis or "Nn"
+        if dis is not None:
+            kw["disallow"] = dis
+        if rng.random() < 0.3:
+            kw["allow"] = rng.choice(["ACGTacgt", "ACGTRYry", "ACGTNn", "ACGTRYKMNn"])
+        if rng.random() < 0.5:
+            a = rng.randint(0, k)
+            kw["split"] = rng.choice([[a], [a, -rng.randint(0, k - a)]])
+        ks = kstream(**kw)
+        if ks.device_plan() is None:
+            assert ks.plan_reason, kw
+            continue
+        ran += 1
+
+        def run(fn):
+            try:
+                return ("ok", list(fn(src)))
+            except Exception as e:  # noqa: BLE001
+                return ("raises", type(e).__name__)
+        want = run(ks.host_lines)
+        assert run(ks) == want, kw
+        if want[0] == "ok":
+            out = tmp_path / "o.txt"
+            assert ks.write(str(out), src) == len(want[1]), kw
+            assert out.read_text().split("\n")[:-1] == want[1], kw
+    assert ran >= 3

@@ -178,7 +178,6 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     assert p["layout"] == "custom" and p["order"] == [2, 1, 0]
     for change, why in ((dict(allow="ACG"), "closed under complement"), (dict(disallow="A"), "closed under complement"),
                         (dict(kmers=[28, 29], sort=False), "several k without --sort"),
-                        (dict(sort=False, mapsoft=False), "placed by position"), (dict(sort=False, expandiupac=True), "placed by position"),
                         (dict(kmers=40, split=[30, -2], complements=False), "outside the krisp_fasta combination"),
                         (dict(kmers=300, split=[30, -2]), "k > 256"), (dict(kmers=120, split=[70, -2]), "flanks outside"),
                         (dict(kmers=40, split=[30, -2], sort=False), "k > 32 without --sort")):
@@ -194,6 +193,9 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     assert kstream(**dict(base, allow="AC", complements=False, disallow=None)).device_plan()["allow"] == "AC"
     assert kstream(**dict(base, allow="ACGTN", disallow=None)).device_plan() is not None   # (N windows survive: the host's specials)
     assert kstream(**dict(base, expandiupac=True, disallow=None)).device_plan()["expand"]
+    # round 5: unsorted streams keep their lower case / expand IUPAC letters too (the host's k-mers placed by position)
+    assert kstream(**dict(base, sort=False, mapsoft=False)).device_plan()["keepcase"]
+    assert kstream(**dict(base, sort=False, expandiupac=True)).device_plan()["expand"]
     p = kstream(**dict(base, sort=False)).device_plan()
     assert p["sorted"] is False and p["geometry"] == (28, 0, 0) and p["fields"] == [25, 1, 2]
 
