@@ -444,11 +444,21 @@ def main():
         except _native.KrispHipError as e:
             comm_probe = {"error": str(e)}
     comm0 = eng.debug_comm() if comm else None
+    selfx = None
     t0 = time.perf_counter()
     ncand = 0
     for _ in range(args.steps):
         ncand = step()
     comm1 = eng.debug_comm() if comm else None      # (before the closing barrier: that is bench.py's, not the step's)
+    if comm and args.transport == "rccl" and not wide and world == 1:
+        # --force-comm at N = 1: one round of the tree with the rank as its own partner, on the real transport -- the step's
+        # candidate list + header through ncclSend / ncclRecv, merged as a received list is (kr_debug_cands_selfexchange)
+        try:
+            before = int(ncand)
+            selfx = {"candidates_before": before, "candidates_after": int(eng.cands_selfexchange(apply_filter=True))}
+            selfx["ok"] = selfx["candidates_after"] == before
+        except _native.KrispHipError as e:
+            selfx = {"error": str(e)}
     barrier()
     dt = time.perf_counter() - t0
     stages = eng.stage_times() if not args.no_stage_timers else {}
@@ -576,7 +586,7 @@ def main():
             "rccl_ranks": eng.comm_rccl_ranks(),     # (ncclCommCount: 0 = no RCCL communicator in this run)
             # the ONE exchange of a step on rank 0 (kr_debug_comm): blocking calls and host time inside kr_cands_reduce +
             # kr_cands_bcast (the time includes waiting for the slowest rank's sorts: the tree is the step's first meeting)
-            "exchange_call_cost": comm_probe,
+            "exchange_call_cost": comm_probe, "exchange_self_round": selfx,
             "exchange": None if not comm or world == 1 else {
                 "ms_per_step": round((comm1["exchange_us"] - comm0["exchange_us"]) / args.steps / 1e3, 4),
                 "host_syncs_per_step": (comm1["syncs"] - comm0["syncs"]) / args.steps,

@@ -387,6 +387,10 @@ int     kr_debug_comm(kr_ctx*, int64_t* out8);
  * calls it): out3[0] all-reduce of three doubles + synchronisation, [1] a send / receive pair of `bytes` to the rank itself
  * + synchronisation, [2] a broadcast of `bytes` + synchronisation */
 int     kr_debug_comm_probe(kr_ctx*, size_t bytes, int reps, double* out3);
+/* one round of the tree with the rank itself as its partner over RCCL: the candidate list + header sent to and received from
+ * itself, merged as a received list is (count read on the device).  What a one-GPU box can show of the exchange on the real
+ * transport; returns the count (unchanged for an unfiltered list) */
+int64_t kr_debug_cands_selfexchange(kr_ctx*, int apply_filter);
 /* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
 int64_t kr_debug_budget_left(kr_ctx*);
 int     kr_debug_budget_set(kr_ctx*, int64_t left);

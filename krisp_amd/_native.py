@@ -113,6 +113,7 @@ SYMBOLS = [
     ("kr_debug_comm", _c.c_int, [_P, _P]),
     ("kr_debug_place", _c.c_int, [_P, _P]),
     ("kr_debug_comm_probe", _c.c_int, [_P, _c.c_size_t, _c.c_int, _P]),
+    ("kr_debug_cands_selfexchange", _c.c_int64, [_P, _c.c_int]),
     ("kr_debug_info", _c.c_int, [_P, _P]),
     ("kr_render_records", _c.c_int64, [_P, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _c.c_size_t, _P,
                                        _c.c_int, _P, _P, _P, _P]),
@@ -632,6 +633,10 @@ class Engine:
         self._check(self.lib.kr_debug_place(self.ctx, _ptr(o)), "kr_debug_place")
         return dict(candidates=int(o[0]), taken=int(o[1]), fastest_ms=[round(float(x), 4) for x in o[2:6]],
                     median_ms=round(float(o[6]), 4), slowest_ms=round(float(o[7]), 4))
+
+    def cands_selfexchange(self, apply_filter=False):
+        """one round of the tree with the rank itself as partner, over RCCL (kr_debug_cands_selfexchange)"""
+        return self._check(self.lib.kr_debug_cands_selfexchange(self.ctx, 1 if apply_filter else 0), "kr_debug_cands_selfexchange")
 
     def comm_probe(self, nbytes=64 << 10, reps=50):
         """microseconds per blocking call of the exchange (kr_debug_comm_probe; RCCL communicators only)"""

@@ -469,6 +469,7 @@ def test_krisp_fasta_over_several_devices_from_one_process(devices, name, tmp_pa
 def test_rccl_communicator_at_world_size_one():
     """RCCL itself on this box: unique id, ncclCommInitRank, all-reduce, barrier, and the exchange
     calls (no partner: they return at once) -- what a one-GPU box can exercise of the RCCL transport"""
+    import numpy as np
     from krisp_amd import _native, synth
     fam = synth.family(8, 1, 1, 60_000, records=2, mu=0.01, snp_every=1000)
     with _native.Engine(device=0) as eng:
@@ -483,6 +484,20 @@ def test_rccl_communicator_at_world_size_one():
         assert eng.cands_bcast() == n0
         nrec = eng.collect([0, 1], fetch=False)
         assert eng.records_gather() == nrec
+        # round 5: ONE round of the tree on the real transport, the rank as its own partner: the list with its header goes
+        # candB -> ncclSend / ncclRecv -> other and is merged as a received list is (count read on the device); an
+        # unfiltered list of 10^4-10^5 candidates comes back as it was, masks included, the filtered one too
+        for filt in (False, True):
+            n1 = eng.intersect([0, 1], [True, False], apply_filter=filt)
+            before = eng.cands().copy()
+            assert n1 == len(before) > (5 if filt else 1000)
+            assert eng.cands_selfexchange(apply_filter=filt) == n1
+            assert np.array_equal(eng.cands(), before)
+        cost = eng.comm_probe(28 << 10, 20)
+        assert 0 < cost["allreduce_sync_us"] < 2000 and 0 < cost["sendrecv_self_sync_us"] < 2000
+        # an empty list travels, too (a message is never shorter than its header)
+        eng.load_cands(before[:0])
+        assert eng.cands_selfexchange() == 0
 
 
 def test_a_failing_rank_stops_every_rank(tmp_path):
