@@ -13,6 +13,7 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+cp "$OUT/bench.json" "$OUT/bench_first_process.json"      # (the box's first process: its placement class may differ from the last one's)
 tail -1 "$OUT/bench.json" | head -c 1500; echo
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats.log" 2>&1
