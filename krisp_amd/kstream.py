@@ -133,12 +133,13 @@ class kstream:
         if len(self.kmers) > 1:
             # several k: one device plan (one sort) per k, the sorted streams merged by the same
             # comparator (unsorted, the windows of every record come k by k: host chain)
-            if self.sort is not True:
-                return self._no_plan("several k without --sort: the windows of a record come k by k")
             plans = [self._plan_one(k) for k in self.kmers]
             if any(p is None for p in plans):
                 return None
-            return dict(multi=plans, strands=plans[0]["strands"], layout="multi", fields=None, geometry=None)
+            # (unsorted, the windows of a record come k by k, kstream.py:631-642: one stream-order pass per k on the
+            # device, put together record by record -- round 5)
+            return dict(multi=plans, strands=plans[0]["strands"], layout="multi", fields=None, geometry=None,
+                        sorted=self.sort is True)
         return self._plan_one(self.kmers[0])
 
     def _plan_one(self, k):
@@ -308,7 +309,7 @@ class kstream:
         c = np.concatenate([[0], np.cumsum(~plain[bases], dtype=np.int64)])
         return np.flatnonzero(c[k:] - c[:-k] == 0)
 
-    def _device_keys(self, sequences, plan):
+    def _device_keys(self, sequences, plan, want_layout=False):
         """-> (sorted keys in the plan's field order, is_rna, host k-mers as window strings) or None when only the host
         chain reproduces the stream (plan_reason says why)."""
         import numpy as np
@@ -353,6 +354,8 @@ class kstream:
                 keys = eng.keys_in_order(0, len(bases))
         if not plan["sorted"]:
             # stream order: (keys, rna, [(window start, its k-mers)], starts of the device's windows) -- _device_blocks interleaves
+            if want_layout:
+                return keys, rna, special, self._device_window_starts(bases, plan), np.flatnonzero(bases == 10)
             return keys, rna, special, (self._device_window_starts(bases, plan) if special else None)
         # host k-mers of plain ACGT (expansions of IUPAC letters) are keys like the device's
         if special and not krisp_combo:
@@ -365,6 +368,46 @@ class kstream:
 
     def _device_blocks(self, sequences, plan):
         """-> (iterator of byte blocks of the output, line count) or None"""
+        if plan.get("multi") and not plan["sorted"]:
+            # several k in stream order: per record, for each k in turn, that k's windows (kstream.py:631-642).  One stream-
+            # order pass per k on the device; a record's share of each pass is cut out by the positions of its separators
+            import numpy as np
+            passes, total, rna, seps = [], 0, None, None
+            for sub in plan["multi"]:
+                got = self._device_keys(sequences, sub, want_layout=True)
+                if got is None:
+                    return None
+                keys, rna, special, starts, seps = got
+                per = 2 if sub["strands"] == 0 else 1
+                assert len(keys) == per * len(starts), (len(keys), len(starts))
+                passes.append((sub, keys, list(special), starts, per))
+                total += int(len(keys)) + sum(len(km) for _, km in special)
+            bounds = np.concatenate([[-1], seps, [np.iinfo(np.int64).max]]).astype(np.int64)
+
+            def blocks():
+                sp_at = [0] * len(passes)
+                for r in range(len(bounds) - 1):
+                    lo_pos, hi_pos = int(bounds[r]) + 1, int(bounds[r + 1])            # the record's characters [lo_pos, hi_pos)
+                    for pi, (sub, keys, special, starts, per) in enumerate(passes):
+                        a = int(np.searchsorted(starts, lo_pos))
+                        b = int(np.searchsorted(starts, hi_pos))
+                        while True:
+                            # the record's special windows of this k, each put in by its position
+                            nxt = special[sp_at[pi]] if sp_at[pi] < len(special) and special[sp_at[pi]][0] < hi_pos else None
+                            upto = b if nxt is None else int(np.searchsorted(starts, nxt[0]))
+                            for x in range(a, upto, _WRITE_CHUNK):
+                                y = min(upto, x + _WRITE_CHUNK)
+                                yield codec.keys_to_fields_bytes(keys[per * x:per * y], sub["fields"], rna)
+                            a = upto
+                            if nxt is None:
+                                break
+                            sp_at[pi] += 1
+                            lines = [self._split_one(w) if self.split is not None else w for w in nxt[1]]
+                            if rna:
+                                lines = [w.replace("T", "U").replace("t", "u") for w in lines]
+                            if lines:
+                                yield ("\n".join(lines) + "\n").encode("latin-1")
+            return blocks(), total
         if plan.get("multi"):
             # several k: every k sorted on the device, the streams merged under the one comparator
             # of `sort -t, -kN,N ...` (listed columns, then the whole line)

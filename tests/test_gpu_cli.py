@@ -1059,6 +1059,9 @@ def test_kstream_unsorted_streams_with_special_windows(seed, tmp_path):
     for trial in range(6):
         k = rng.choice([3, 6, 11, 20, 31])
         kw = dict(kmers=k, sort=False)
+        if trial % 3 == 2:                  # several k: per record, each k's windows in turn (kstream.py:631-642)
+            kw["kmers"] = rng.sample([3, 5, 8, 13, 21, 32], rng.randint(2, 3))
+            k = min(kw["kmers"])
         kw.update(rng.choice([dict(complements=True), dict(canonicals=True), {}]))
         kw.update(rng.choice([dict(mapsoft=True), dict(omitsoft=True), {}]))
         dis = rng.choice(["Nn", "Nn", "N", None, "RrNn", "X-Nn"])

@@ -177,7 +177,6 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     p = kstream(**dict(base, sortcols=[2, 1])).device_plan()
     assert p["layout"] == "custom" and p["order"] == [2, 1, 0]
     for change, why in ((dict(allow="ACG"), "closed under complement"), (dict(disallow="A"), "closed under complement"),
-                        (dict(kmers=[28, 29], sort=False), "several k without --sort"),
                         (dict(kmers=40, split=[30, -2], complements=False), "outside the krisp_fasta combination"),
                         (dict(kmers=300, split=[30, -2]), "k > 256"), (dict(kmers=120, split=[70, -2]), "flanks outside"),
                         (dict(kmers=40, split=[30, -2], sort=False), "k > 32 without --sort")):
@@ -196,6 +195,8 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     # round 5: unsorted streams keep their lower case / expand IUPAC letters too (the host's k-mers placed by position)
     assert kstream(**dict(base, sort=False, mapsoft=False)).device_plan()["keepcase"]
     assert kstream(**dict(base, sort=False, expandiupac=True)).device_plan()["expand"]
+    p = kstream(**dict(base, kmers=[28, 29], sort=False)).device_plan()          # several k in stream order: a pass per k
+    assert p["sorted"] is False and [q["k"] for q in p["multi"]] == [28, 29]
     p = kstream(**dict(base, sort=False)).device_plan()
     assert p["sorted"] is False and p["geometry"] == (28, 0, 0) and p["fields"] == [25, 1, 2]
 
