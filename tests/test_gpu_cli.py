@@ -1016,6 +1016,8 @@ def test_streaming_flow_equals_the_in_core_flow(case, tmp_path, monkeypatch):
     if case == "slices":
         monkeypatch.setenv("KR_SLICE_BASES", "1")
     labels = [KF.simplename(f) for f in ing]
+    monkeypatch.delenv("KRISP_STREAM_BATCH", raising=False)          # (the suite may run with the streaming flow forced everywhere)
+    monkeypatch.delenv("KRISP_HBM_BUDGET", raising=False)
     want, wstats = KF.find_regions(ing, outg, L, R, k)
     assert not wstats.get("streamed")
     want_text = _render_groups(want, labels)
