@@ -857,7 +857,9 @@ def test_text_size_estimates_for_the_memory_plan(tmp_path):
     (tmp_path / "big.fa.gz").write_bytes(fake)
     assert fasta.estimate_text_bytes(str(tmp_path / "big.fa.gz")) == 100 + (1 << 32)
     (tmp_path / "block.fa.gz").write_bytes(_bgzf(t))
-    assert fasta.estimate_text_bytes(str(tmp_path / "block.fa.gz")) == 5 * os.path.getsize(tmp_path / "block.fa.gz")
+    assert fasta.estimate_text_bytes(str(tmp_path / "block.fa.gz")) == len(t)          # (BGZF: the members' ISIZE words, exact)
+    (tmp_path / "half.fa.gz").write_bytes(_bgzf(t)[:-30] + b"x" * 30)                   # (not BGZF all the way: the guess)
+    assert fasta.estimate_text_bytes(str(tmp_path / "half.fa.gz")) == 5 * os.path.getsize(tmp_path / "half.fa.gz")
 
 
 def test_bz2_blocks_decode_side_by_side(tmp_path, monkeypatch):
