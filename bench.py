@@ -335,6 +335,11 @@ def main():
                     help="self-launched ranks (--gpus N without a launcher) are ended after this many seconds")
     args = ap.parse_args()
 
+    # RCCL writes its version banner (NCCL_DEBUG=VERSION, what these boxes export) and its warnings to STDOUT, in front of
+    # the ONE JSON line: errors only, unless the caller asked for more than the banner
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "ERROR"
+
     from krisp_amd import distributed as D
     if args.gpus > 1 and not D.launched():
         sys.exit(self_launch(args.gpus, args.launch_timeout))       # (before anything here touches the GPU)
