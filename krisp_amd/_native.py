@@ -292,8 +292,16 @@ def render_windows(rows, cand, genome, label_of, label_text, label_in, L, D, R, 
         lib.kr_text_free(align)
 
 
+def _quiet_rccl():
+    """RCCL prints its version banner (NCCL_DEBUG=VERSION, what some boxes export) and its warnings on STDOUT -- where the
+    command line writes its CSV and bench.py its one JSON line: errors only, unless the caller asked for more than the banner"""
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "ERROR"
+
+
 def comm_unique_id():
     """the RCCL unique id (rank 0 makes it, every rank passes it to Engine.comm_init)"""
+    _quiet_rccl()
     lib = load()
     buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
     rc = lib.kr_comm_unique_id(_ptr(buf))
@@ -489,6 +497,7 @@ class Engine:
     # ---- multi-GPU exchange (one process / context per GPU; krisp_amd/distributed.py does the rendezvous)
     def comm_init(self, rank, world, comm_id):
         """RCCL communicator from the unique id rank 0 made (comm_unique_id)"""
+        _quiet_rccl()
         buf = np.frombuffer(comm_id, dtype=np.uint8)
         assert len(buf) == COMM_ID_BYTES
         self._check(self.lib.kr_comm_init(self.ctx, rank, world, _ptr(buf)), "kr_comm_init")

@@ -169,6 +169,10 @@ def connect(engine, rank, world, transport="rccl", path=None, timeout_s=600):
     path = path or rendezvous_path(world)
     if transport not in ("rccl", "dir"):
         raise ValueError(f"unknown transport {transport!r}")
+    if transport == "rccl" and os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        # (RCCL prints its version banner and its warnings on STDOUT, where the command line writes its CSV and bench.py its
+        # one JSON line: errors only, unless the caller asked for more than the banner)
+        os.environ["NCCL_DEBUG"] = "ERROR"
     if transport == "rccl" and world == 1:
         engine.comm_init(0, 1, _native.comm_unique_id())
         return
