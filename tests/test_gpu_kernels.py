@@ -78,6 +78,19 @@ def test_sort_geometries(N, K, L, D, R):
     _check_sorted(N, K, text, L, D, R, stages=True)
 
 
+@pytest.mark.parametrize("sb", [None, 1])
+@pytest.mark.parametrize("L,D,R", [(16, 16, 0), (16, 8, 8), (16, 1, 0), (17, 0, 15), (20, 6, 6), (24, 4, 4), (31, 1, 0),
+                                   (31, 0, 1), (32, 0, 0), (30, 1, 1), (19, 2, 3), (15, 1, 16), (15, 16, 1)])
+def test_pass_1_generator_that_shifts_the_word_string_once(N, K, L, D, R, sb):
+    """k_scatter1p<., ., 1> (p1_fast_keys: `left` of 16 bases or more, both strands): every width of the three fields
+    around its limits, window lengths from 17 to 32, with and without key-space slices (its BIG form is their pass 0);
+    L = 15 beside them takes the general generator.  Texts whose length is no multiple of a code word, with N runs,
+    soft-masked stretches and several records."""
+    text = _rand_text(4000 + 37 * L + 5 * D + R, 61_003 + L, b"ACGT" * 14 + b"acgtNn", records=6)
+    for omit in (False, True):
+        _check_sorted(N, K, text, L, D, R, omit=omit, stages=sb is None, slice_bases=sb)
+
+
 @pytest.mark.parametrize("n,L,D,R", [
     (300_000, 25, 1, 2),      # fan-out 2^9: fine offsets straight from the codes (k_hist16)
     (300_000, 5, 1, 2),       # 2 L = 10 >= 9: still k_hist16, the top bits end inside `left`
