@@ -450,6 +450,7 @@ def main():
             comm_probe = {"error": str(e)}
     comm0 = eng.debug_comm() if comm else None
     selfx = None
+    barrier()                           # (the timed region starts with every rank here and its stream drained)
     t0 = time.perf_counter()
     ncand = 0
     for _ in range(args.steps):
