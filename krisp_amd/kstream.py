@@ -115,7 +115,8 @@ class kstream:
         --expand-iupac; split None, [a], [a, -b] (a, b >= 0); sorted with ANY
         --sort-cols -- GNU sort falls back to the whole line, so a column list is a permutation of the fields followed
         by line order, and the key holds the fields in that order (kr_set_field_order; the krisp_fasta order (first,
-        last, middle) keeps its own layout and kernels) -- or unsorted (stream order).  k > 32: the krisp_fasta
+        last, middle) keeps its own layout and kernels) -- or unsorted (stream order: the device's k-mers in window
+        order, the host's special windows placed among them by position; several k record by record).  k > 32: the krisp_fasta
         combination through the wide path (flanks <= 64, k <= 256).
         The device carries windows of plain ACGT (upper case only when lower case is kept or omitted); a window holding
         anything else that the chain would keep -- IUPAC letters, lower case under 'neither', other characters -- runs
@@ -123,9 +124,8 @@ class kstream:
         Not on the device, with the reason in `plan_reason`:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
             formed before the filters);
-          * unsorted streams (no --sort) of several k, or of inputs that hold characters beyond ACGTN (their k-mers
-            would have to be placed by position, not by value), or with --expand-iupac / kept lower case;
-          * k > 32 outside the krisp_fasta combination, flanks > 64, k > 256;
+          * more than two split points;
+          * k > 32 outside the krisp_fasta combination or without --sort, flanks > 64, k > 256;
           * a custom column order on an input large enough to need key-space slices (> 2^28 bases: decided at run time)."""
         self.plan_reason = None
         if self.kmers is None or len(self.kmers) < 1:
