@@ -114,7 +114,12 @@ int kr_set_field_order(kr_ctx*, const int widths[3], const int order[3]);
 
 /* H2D copy of one genome's text + all device allocations it needs. */
 int kr_genome_upload(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
-/* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous. */
+/* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous.  Under KR_OPT_LAZY_ORDER (the default) the
+ * call ends behind the partition into fine buckets (<= 1600 keys on average, the bucket grid all genomes of a context
+ * share); the order INSIDE the buckets -- the reference's `sort` has no such half-way state, kstream.py:83-119 -- is made
+ * by the first reader that needs it: kr_genome_fetch_keys / kr_cands_probe for the whole genome, kr_intersect for its
+ * anchor genome only (the other genomes' keys are looked up by hashing inside a bucket, in whatever order they lie),
+ * kr_collect for the buckets its candidates touch.  Every call returns what it returns with the option off. */
 int kr_genome_sort(kr_ctx*, int genome_id);
 /* upload + sort + sync; returns the number of k-mer records (>= 0). */
 int64_t kr_genome_add(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
@@ -333,6 +338,8 @@ enum { KR_OPT_SLICE_BASES = 1,       /* -1 automatic; 0..4: sort every genome in
                                         automatic -- one lane until the context has sorted 16 genomes (a lane costs ~10 ms to set
                                         up, more than a one-shot run gets back), 3 from then on.  Key-space slices use one lane
                                         whatever the setting, kr_wide_run two when more than one is asked for.  May be set at any time */
+       KR_OPT_LAZY_ORDER = 10,       /* 1 (default): kr_genome_sort stops at the fine buckets, the LDS sort runs where a reader needs
+                                        the order (see kr_genome_sort); 0: every sort ends with it (rounds 1-5) */
        KR_OPT_WIDE_ORDERED = 6 };    /* wide path: 0 (default) flanks of >= 20 bases are numbered through minimizer buckets (look-ups
                                         of neighbouring windows share memory sectors): the same groups and hits, but `cand` no longer
                                         ascends with (left, right); 1: order-preserving ranks, groups in the reference's order */
@@ -373,7 +380,10 @@ double  kr_debug_copy_gbps(kr_ctx*, size_t bytes, int reps);
 const char* kr_debug_copy_which(kr_ctx*);
 /* the pipelined intersect kernels: items that went to the chunk kernel (oversized), slices redone by chunks,
  * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
- * now; out[6..7] = 0 */
+ * now; out[6..7] = intersections that left their late genomes to the probe, candidates the latest of them probed */
+/* KR_OPT_LAZY_ORDER's counters: out[0] LDS sorts of whole slices kr_genome_sort left out, [1] made later (anchor, fetch, probe),
+ * [2] kr_collect calls that sorted only the buckets their candidates touch, [3] the option's value */
+int     kr_debug_lazy(kr_ctx*, int64_t* out4);
 int     kr_debug_isect(kr_ctx*, int64_t* out8);
 /* the latest placement search of the pass-1 output buffers: out8[0] candidates probed, [1] buffers handed to the sort lanes,
  * [2..5] probe milliseconds of the four fastest candidates, [6] the median, [7] the slowest (bench.py prints them: which

@@ -26,6 +26,7 @@ SOFT_MAP, SOFT_OMIT = 0, 1
 OPT_SLICE_BASES, OPT_GENERIC_INTERSECT, OPT_ISECT_FORMAT, OPT_ABLATE, OPT_WIDE_SLOTS, OPT_WIDE_ORDERED, OPT_PLACE_TRIES = 1, 2, 3, 4, 5, 6, 7
 OPT_ISECT_KERNEL = 8
 OPT_LANES = 9
+OPT_LAZY_ORDER = 10
 ERR_KEY, ERR_HOST = -5, -6
 STRANDS_BOTH, STRANDS_FORWARD, STRANDS_CANONICAL = 0, 1, 2
 STAGES = ["pack", "hist8", "reduce8", "scatter1", "hist2", "scan2", "scatter2", "chunks", "localsort",
@@ -119,6 +120,7 @@ SYMBOLS = [
                                        _c.c_int, _P, _P, _P, _P]),
     ("kr_text_free", None, [_P]),
     ("kr_debug_isect", _c.c_int, [_P, _P]),
+    ("kr_debug_lazy", _c.c_int, [_P, _P]),
     ("kr_debug_budget_left", _c.c_int64, [_P]),
     ("kr_debug_budget_set", _c.c_int, [_P, _c.c_int64]),
 ]
@@ -616,6 +618,13 @@ class Engine:
         self.lib.kr_debug_isect(self.ctx, _ptr(o))
         return dict(chunk_kernel_items=int(o[0]), slices_redone=int(o[1]), threads=int(o[2]), buckets_per_item_log2=int(o[3]),
                     heads32=int(o[4]), sort_lanes=int(o[5]), splits=int(o[6]), probed=int(o[7]))
+
+    def debug_lazy(self):
+        """KR_OPT_LAZY_ORDER's counters (kr_debug_lazy): LDS sorts of whole slices the sorts left out, made later, collects
+        that sorted the touched buckets only, the option's value"""
+        o = np.zeros(4, dtype=np.int64)
+        self.lib.kr_debug_lazy(self.ctx, _ptr(o))
+        return dict(skipped=int(o[0]), ordered_later=int(o[1]), touch_collects=int(o[2]), on=int(o[3]))
 
     def copy_gbps(self, nbytes=1 << 30, reps=10):
         v = self.lib.kr_debug_copy_gbps(self.ctx, nbytes, reps)
