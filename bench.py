@@ -331,6 +331,10 @@ def main():
                     help="dir: rehearse the N > 1 flow with several ranks sharing the visible GPU (messages through files)")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the RCCL communicator even at world size 1 (plumbing self-test)")
+    ap.add_argument("--no-configs3", action="store_true",
+                    help="at --gpus 8 without --config: leave out the second block that times BASELINE configs[3]'s load")
+    ap.add_argument("--force-configs3", action="store_true", help="time the configs[3] block at any world size (tests)")
+    ap.add_argument("--configs3-length", type=int, default=0, help="genome length of that block (tests; default: configs[3]'s 100 Mbp)")
     ap.add_argument("--launch-timeout", type=int, default=1500,
                     help="self-launched ranks (--gpus N without a launcher) are ended after this many seconds")
     args = ap.parse_args()
@@ -456,6 +460,8 @@ def main():
     for _ in range(args.steps):
         ncand = step()
     comm1 = eng.debug_comm() if comm else None      # (before the closing barrier: that is bench.py's, not the step's)
+    barrier()
+    dt = time.perf_counter() - t0                   # (the K steps and their closing barrier, nothing else: ADVICE r5)
     if comm and args.transport == "rccl" and not wide and world == 1:
         # --force-comm at N = 1: one round of the tree with the rank as its own partner, on the real transport -- the step's
         # candidate list + header through ncclSend / ncclRecv, merged as a received list is (kr_debug_cands_selfexchange)
@@ -465,8 +471,7 @@ def main():
             selfx["ok"] = selfx["candidates_after"] == before
         except _native.KrispHipError as e:
             selfx = {"error": str(e)}
-    barrier()
-    dt = time.perf_counter() - t0
+        barrier()
     stages = eng.stage_times() if not args.no_stage_timers else {}
     kmers_local = int(sum(eng.wide_fetch(_native.WIDE_COUNTS))) if wide else sum(eng.count(g) for g in ids)
     # measured streaming-copy rate of this box: the best of every copy form x grid the library times (kr_debug_copy_gbps),
@@ -484,6 +489,47 @@ def main():
         records_total = int(eng.comm_allreduce([float(nrec[0])], "sum")[0])
     else:
         kmers_total, records_total = kmers_local, nrec[0]
+
+    # the driver's sweep runs `--gpus 8` without --config, i.e. configs[1]'s per-GPU load (the weak-scaling
+    # series).  BASELINE quotes configs[3] -- 32 x 100 Mbp, 4 per GPU -- ON 8 GPUs: at that world size the same process times
+    # that load too (the first workload's genomes freed, the context's parameters set again), so the one 8-GPU run there may
+    # be yields the BASELINE-quoted config in the same line (`configs3`).  Nothing of it is inside the region `value` times.
+    configs3 = None
+    c3 = CONFIGS[3]
+    if (args.config is None and not custom and world == c3["gpus"] and gen_8d and not args.no_configs3) or args.force_configs3:
+        try:
+            for g in ids:
+                eng.free(g)
+            g3 = make_genomes(c3["gen"], rank, world, c3["per_gpu"], args.configs3_length or c3["length"])
+            eng.set_params(*c3["ldr"], omit_soft=False, max_bases=max(len(t) for _, _, t in g3))
+            ids3 = []
+            for g, ing, text in g3:
+                eng.upload(g, text)
+                ids3.append(g)
+            flags3 = [ing for _, ing, _ in g3]
+            del g3
+            st3, wu3 = 5, 2
+            for _ in range(wu3):
+                D.sharded_step(eng, ids3, flags3, world, apply_filter=True, collect=True)
+            barrier()
+            t3 = time.perf_counter()
+            n3 = 0
+            for _ in range(st3):
+                n3, _r3 = D.sharded_step(eng, ids3, flags3, world, apply_filter=True, collect=True)
+            barrier()
+            dt3 = time.perf_counter() - t3
+            k3 = sum(eng.count(g) for g in ids3)
+            if comm and world > 1:
+                dt3 = float(eng.comm_allreduce([dt3], "max")[0])
+                k3 = int(eng.comm_allreduce([float(k3)], "sum")[0])
+            configs3 = {"workload": f"BASELINE configs[3]: {c3['what']}" + ("" if world == c3["gpus"] else
+                                    f" -- its per-GPU load on {world} GPU(s)")
+                                    + ("" if not args.configs3_length else f", genomes of {args.configs3_length / 1e6:g} Mbp (--configs3-length)"),
+                        "value": k3 * st3 / dt3, "unit": "k-mers/s", "n_gpus": world, "steps": st3, "warmup": wu3,
+                        "ms_per_step": dt3 / st3 * 1e3, "kmers_per_step": k3, "candidates": int(n3),
+                        "note": "timed after the main workload of this line, in the same process and context; not part of `value`"}
+        except _native.KrispHipError as e:
+            configs3 = {"error": str(e)}
 
     def gpu_check(want):
         """the oracle's sorted keys / candidates / records of the full workload against what the last timed step left in
@@ -558,17 +604,43 @@ def main():
                                          "frac": round(sg / HBM_PEAK_GBPS, 4), "frac_of_copy_peak": round(sg / copy_gbps, 4)}
                 except Exception as e:  # noqa: BLE001
                     traffic_meta = {"error": str(e)}
-            # top level = the dominant kernel BY ITSELF (one sort lane, calibration steps of this run; the figure the
-            # rocprofv3 summary of `bench.py --lanes 1` shows); `live` = the same kernel inside the timed region, where
-            # its launches share the device with other genomes' kernels; `step` = the whole step on measured bytes
-            roof = {"bound": "hbm", "kernel": _native.STAGE_KERNELS[dom], "achieved": round(alone, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(alone / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(alone_ms, 4), "launches": calib[dom][1] * ncal,
-                    "how": "algorithmic bytes per launch / average launch time (HIP events on the library's stream around each "
-                           "launch) of the dominant kernel by itself: calibration steps of this run with one sort lane",
-                    "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(alone / copy_gbps, 4),
-                    "copy_peak_which": copy_which, "copy_peak_guide": 6290.0,
-                    "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch, "key_space_slices": nslices,
+            # Schema 6: the TOP LEVEL is the whole step -- the figure tied to the driver-timed `value`:
+            # HBM bytes of one step / ms_per_step of this run.  Bytes: measured (PMC, all kernels of a step) when
+            # profiles/traffic*.json was taken with this very build, else the design's algorithmic bytes per k-mer
+            # (`basis` says which).  `kernel` = the dominant kernel BY ITSELF (one sort lane, calibration
+            # steps of this run: what `rocprofv3 --stats` of `bench.py --lanes 1` shows), `live` = the same kernel inside
+            # the timed region, where its launches share the device with other genomes' kernels.
+            lazy = eng.debug_lazy()
+            alg_bpk = None
+            if not wide:
+                sb = stage_bytes
+                # (KR_OPT_LAZY_ORDER: the LDS sort reads and writes the anchor genome only -- one of per_gpu)
+                ls_share = (1.0 / per_gpu) if lazy["on"] and lazy["skipped"] else 1.0
+                alg_bpk = (sb["pack"] + sb["hist8"] + sb["scatter1"] + (2 * 0.1875 if nslices == 1 else sb["hist2"]) + sb["scatter2"]
+                           + sb["localsort"] * ls_share + sb["intersect"])
+            if step_roof is not None:
+                top_bytes, basis = step_roof["bytes_per_step"], "measured: PMC bytes of all kernels of one step (profiles/, this build)"
+            elif alg_bpk is not None:
+                top_bytes, basis = alg_bpk * kmers_local, "algorithmic bytes per k-mer of the design (no PMC file of this build)"
+            else:
+                top_bytes, basis = stage_bytes[dom] * per_launch * calib[dom][1], "algorithmic bytes of the dominant stage only"
+            top_gbps = top_bytes / (ms_per_step * 1e-3) / 1e9
+            roof = {"bound": "hbm", "scope": "step", "achieved": round(top_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(top_gbps / HBM_PEAK_GBPS, 4),
+                    "traffic": step_roof["bytes_per_step"] if step_roof is not None else None,
+                    "basis": basis, "bytes_per_step": round(top_bytes), "bytes_per_kmer": round(top_bytes / max(kmers_local, 1), 2),
+                    "algorithmic_bytes_per_kmer": None if alg_bpk is None else round(alg_bpk, 2),
+                    "how": "HBM bytes of one step / ms_per_step of the timed region (the figure `value` follows from)",
+                    "copy_peak_measured": round(copy_gbps, 1), "frac_of_copy_peak": round(top_gbps / copy_gbps, 4),
+                    "copy_peak_which": copy_which, "copy_peak_guide": 6290.0, "key_space_slices": nslices,
+                    "lazy_order": lazy,
+                    "kernel": {"name": _native.STAGE_KERNELS[dom], "achieved": round(alone, 1), "frac": round(alone / HBM_PEAK_GBPS, 4),
+                               "traffic": traffic, "avg_launch_ms": round(alone_ms, 4), "launches": calib[dom][1] * ncal,
+                               "bytes_per_kmer": stage_bytes[dom], "kmers_per_launch": per_launch,
+                               "frac_of_copy_peak": round(alone / copy_gbps, 4),
+                               "how": "algorithmic bytes per launch / average launch time (HIP events on the library's stream "
+                                      "around each launch) of the dominant kernel by itself: calibration steps of this run with "
+                                      "one sort lane"},
                     "live": {"what": f"the same kernel inside the timed region ({lanes} sort lane(s)"
                                      + ("" if lanes <= 1 or wide else ": its launches run beside the kernels of other genomes' "
                                         "sorts, so a launch lasts longer while the step gets shorter") + ")",
@@ -581,10 +653,10 @@ def main():
                     "stage_ms_per_step_calibration": {s: round(v[0], 4) for s, v in calib.items()}}
         name = baseline_config_name(cfg, custom, world, args.independent, args.masked, args.mu, args.records, args.snp_every)
         out = {
-            # schema 5 (round 5): as round 4 (`roofline` top level = the dominant kernel by itself, `roofline.live` = the same
-            # kernel inside the timed region, `roofline.step` = all kernels on measured bytes) + `copy_peak_which`,
-            # `config.baseline_config_index`, `oracle_match`
-            "schema": 5,
+            # schema 6 (round 6): `roofline` top level = the whole STEP (bytes of one step / ms_per_step: the figure tied to the
+            # driver-timed value), `roofline.kernel` = the dominant kernel by itself, `roofline.live` = the same kernel inside
+            # the timed region, `roofline.step` = the PMC details; `configs3` = BASELINE configs[3]'s load in the same run at 8 GPUs
+            "schema": 6,
             "metric": f"k-mers/s sorted+intersected at k={k}", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -619,11 +691,12 @@ def main():
                        "parallelism": f"genome-sharded x{world}" + ("" if world == 1 else
                                       f" + tree-reduce of candidates ({args.transport})")},
             "roofline": roof,
+            "configs3": configs3,
         }
         if world == 1 and not args.no_cpu_baseline and wide:
             out["cpu_baseline"] = cpu_baseline_wide(config, L, Dg, R, per_gpu, args.mu, args.records, args.snp_every)
         elif world == 1 and not args.no_cpu_baseline:
-            check = gpu_check if gen_8d and not args.no_collect else None      # (the CPU sample is 8(d)'s generator)
+            check = gpu_check if gen_8d and not args.no_collect and configs3 is None else None      # (the CPU sample is 8(d)'s generator; a configs3 block has replaced the genomes)
             out["cpu_baseline"] = cpu_baseline(config, L, Dg, R, args.cpu_length, length, per_gpu, gpu_check=check)
             out["oracle_match"] = out["cpu_baseline"].pop("oracle_match", None)
         else:

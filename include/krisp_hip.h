@@ -176,6 +176,13 @@ int     kr_comm_world(kr_ctx*);
 /* ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount); 0 without one (no communicator, or
  * the file transport): bench.py prints it, so a line says whether xGMI carried the exchange */
 int     kr_comm_rccl_ranks(kr_ctx*);
+/* The exchange's deadline.  RCCL's calls have no timeout; every communicator of this library has a watchdog thread
+ * (csrc/h_comm.inc): while an exchange call is in progress it polls ncclCommGetAsyncError, and on an asynchronous error or
+ * `seconds` after the call began it aborts the communicator (ncclCommAbort) -- the call returns KR_ERR_STATE / KR_ERR_HIP,
+ * later exchange calls KR_ERR_STATE; a call that still does not return ends the process with status 124.  The file
+ * transport waits `seconds` for a message.  Default: the environment's KRISP_COMM_TIMEOUT, else 600.  (The reference's tree
+ * runs inside one multiprocessing pool, intersectAmplicons.py:256-307: a dead worker raises there.) */
+int     kr_comm_set_timeout(kr_ctx*, int seconds);
 int     kr_comm_barrier(kr_ctx*);                               /* syncs the stream, then all ranks meet */
 /* vals[0..n) reduced over all ranks, n <= 8: op 0 = sum, 1 = max; the result on every rank */
 int     kr_comm_allreduce(kr_ctx*, double* vals, int n, int op);
@@ -381,6 +388,9 @@ const char* kr_debug_copy_which(kr_ctx*);
 /* the pipelined intersect kernels: items that went to the chunk kernel (oversized), slices redone by chunks,
  * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
  * now; out[6..7] = intersections that left their late genomes to the probe, candidates the latest of them probed */
+/* 0 for a product build; else the result-changing experiment switches the library was compiled with (bit 0 -DKR_EXPERIMENTS,
+ * 1 KR_ABLATE, 2 I3_ABL, 3 P2_ABL, 4 LS2_NORANK, 5 KR_EXP_NOLOOKUP: csrc/k_keys.inc).  No context, no GPU needed. */
+int     kr_build_experiments(void);
 /* KR_OPT_LAZY_ORDER's counters: out[0] LDS sorts of whole slices kr_genome_sort left out, [1] made later (anchor, fetch, probe),
  * [2] kr_collect calls that sorted only the buckets their candidates touch, [3] the option's value */
 int     kr_debug_lazy(kr_ctx*, int64_t* out4);
@@ -401,6 +411,9 @@ int     kr_debug_comm_probe(kr_ctx*, size_t bytes, int reps, double* out3);
  * itself, merged as a received list is (count read on the device).  What a one-GPU box can show of the exchange on the real
  * transport; returns the count (unchanged for an unfiltered list) */
 int64_t kr_debug_cands_selfexchange(kr_ctx*, int apply_filter);
+/* test aid for the communicator's watchdog: a receive nobody sends to + the synchronisation behind it; returns when the
+ * watchdog has aborted the communicator (KR_ERR_STATE) or RCCL has refused the call (KR_ERR_HIP); the communicator is spent */
+int     kr_debug_comm_hang(kr_ctx*);
 /* test aids: bytes left of the context's HBM budget (-1 = no budget); make `left` bytes remain from now on */
 int64_t kr_debug_budget_left(kr_ctx*);
 int     kr_debug_budget_set(kr_ctx*, int64_t left);

@@ -121,6 +121,9 @@ SYMBOLS = [
     ("kr_text_free", None, [_P]),
     ("kr_debug_isect", _c.c_int, [_P, _P]),
     ("kr_debug_lazy", _c.c_int, [_P, _P]),
+    ("kr_build_experiments", _c.c_int, []),
+    ("kr_comm_set_timeout", _c.c_int, [_P, _c.c_int]),
+    ("kr_debug_comm_hang", _c.c_int, [_P]),
     ("kr_debug_budget_left", _c.c_int64, [_P]),
     ("kr_debug_budget_set", _c.c_int, [_P, _c.c_int64]),
 ]
@@ -651,6 +654,14 @@ class Engine:
         self._check(self.lib.kr_debug_place(self.ctx, _ptr(o)), "kr_debug_place")
         return dict(candidates=int(o[0]), taken=int(o[1]), fastest_ms=[round(float(x), 4) for x in o[2:6]],
                     median_ms=round(float(o[6]), 4), slowest_ms=round(float(o[7]), 4))
+
+    def comm_set_timeout(self, seconds):
+        """the exchange's deadline: the watchdog aborts the communicator `seconds` after an exchange call began (kr_comm_set_timeout)"""
+        self._check(self.lib.kr_comm_set_timeout(self.ctx, int(seconds)), "kr_comm_set_timeout")
+
+    def debug_comm_hang(self):
+        """test aid: a receive without a sender; raises once the watchdog has aborted the communicator (kr_debug_comm_hang)"""
+        return self._check(self.lib.kr_debug_comm_hang(self.ctx), "kr_debug_comm_hang")
 
     def cands_selfexchange(self, apply_filter=False):
         """one round of the tree with the rank itself as partner, over RCCL (kr_debug_cands_selfexchange)"""

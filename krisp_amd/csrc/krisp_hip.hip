@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <condition_variable>
 #include <cerrno>
 #include <map>
 #include <memory>

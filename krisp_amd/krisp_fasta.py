@@ -500,9 +500,17 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
     read_s = [None]
     maxb = [max_bases]
 
+    # the first batch must hold both sides when there are two: with one side only nothing prunes, and its candidate list
+    # is every (left,right) pair of its genomes (more than 2^32 entries at 3 Gbp -- the library refuses such a
+    # list, kr_intersect: KR_ERR_CAPACITY)
+    first_min = 2 if (ing and outg and apply_f) else 1
+
     def batches(bsz):
-        for a in range(0, n, bsz):
-            yield order[a:a + bsz]
+        a = 0
+        while a < n:
+            m = max(bsz, first_min) if a == 0 else bsz
+            yield order[a:a + m]
+            a += m
 
     def load_batch(ids_b, futs, first_pass):
         """texts -> device, sorted; a batch that does not fit after all is given back whole (KrispHipError, code capacity)"""
@@ -518,9 +526,9 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
         try:
             for g in ids_b:
                 text, universal = texts.pop(g)
+                done.append(g)          # (before the ingest: a genome that fails half way holds buffers, too -- ADVICE r5)
                 _n, r, sp = fasta.ingest_on_device(eng, g, text, universal, k, omit_soft)
                 del text
-                done.append(g)
                 if first_pass:
                     rna[g] = r
                     specials[g] = [codec.split_window(w, Le, De, Re) for w in sp]
@@ -529,7 +537,10 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
                 counts[g] = eng.count(g)
         except _native.KrispHipError:
             for g in done:
-                eng.free(g)
+                try:
+                    eng.free(g)
+                except _native.KrispHipError:
+                    pass
             raise
 
     def run_pass(bsz, first_pass, work):
@@ -547,7 +558,15 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
             except _native.KrispHipError as e:
                 if e.code != _native.ERR_CAPACITY or len(ids_b) == 1:
                     raise
+                if first_pass and running[0] is None and len(ids_b) <= first_min:
+                    err = _native.KrispHipError(
+                        f"the device cannot hold one ingroup and one outgroup genome sorted at once ({e}); the first batch "
+                        "needs both sides for the diagnostic filter to prune")
+                    err.code = e.code
+                    raise err from e
                 half = (len(ids_b) + 1) // 2
+                if first_pass and running[0] is None:
+                    half = max(half, first_min)
                 todo = [ids_b[:half], ids_b[half:]] + todo
                 for g in ids_b:
                     futs[g] = pool.submit(fasta.read_text, files[g])
@@ -559,34 +578,32 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
                 del futs[g]
             stats["batches"] += 1
 
-    running = [None]
-    eager = [True]
+    running = [None]        # number of running candidates; the list itself stays on the device between the batches of pass 1
+    eager = [True]          # (kr_genome_free does not touch it: no copy to the host and back per batch -- ADVICE r5)
     kept = []
 
     def pass1(ids_b):
         bflags = [flags[g] for g in ids_b]
         if running[0] is None:
-            eng.intersect(ids_b, bflags, apply_filter=apply_f)
+            running[0] = eng.intersect(ids_b, bflags, apply_filter=apply_f)
         else:
             # (a later batch looks the running candidates up in its genomes -- kr_cands_probe: presence in every genome,
             # their diagnostic bases into the masks, the filter -- instead of being intersected whole: the candidate list
             # of a batch that holds one side only is every prefix of its genomes, 24 bytes each)
-            eng.load_cands(running[0])
-            eng.probe_cands(ids_b, bflags, apply_filter=apply_f)
-        running[0] = eng.cands().copy()
+            running[0] = eng.probe_cands(ids_b, bflags, apply_filter=apply_f)
         if verbose:
             for g in ids_b:
                 print(f"=> Extracted and sorted {counts[g]:,} {k}-kmers from {files[g]}", file=sys.stderr)
-        if quirk_all_fail or not len(running[0]):
+        if quirk_all_fail or not running[0]:
             return
-        if eager[0] and len(running[0]) <= STREAM_EAGER_MAX:
+        if eager[0] and running[0] <= STREAM_EAGER_MAX:
             kept.append(eng.collect(sorted(ids_b, key=lambda g: rank_of[g])))
         else:
             eager[0] = False
             kept.clear()
 
     run_pass(batch, True, pass1)
-    final = running[0] if running[0] is not None else np.empty(0, dtype=_native.CAND)
+    final = eng.cands().copy() if running[0] else np.empty(0, dtype=_native.CAND)
     if any(rna) and not all(rna):
         raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
     touched = {(l, r) for sp in specials for (l, d, r) in sp} if not quirk_all_fail else set()

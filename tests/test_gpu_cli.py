@@ -500,6 +500,120 @@ def test_rccl_communicator_at_world_size_one():
         assert eng.cands_selfexchange() == 0
 
 
+TREE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["KR_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["KR_ROOT"], "tests"))
+import torch.distributed as dist
+from krisp_amd import _native, distributed as D
+import dist_tree_reference as T
+
+rank, _, world = D.env_rank_world()
+filt = os.environ["KR_FILTER"] == "1"
+# the SAME per-rank candidate lists for both trees: a common pool of prefixes, every rank keeps a random 80 % of it (so the
+# intersection is non-trivial), with random 4-bit base sets in a random side's mask
+pool = np.unique(np.random.default_rng(7).integers(0, 1 << 54, 6000, dtype=np.uint64) << np.uint64(10))
+rng = np.random.default_rng(100 + rank)
+keep = rng.random(len(pool)) < (0.8 if rank else 0.9)
+mine = np.zeros(int(keep.sum()), dtype=_native.CAND)
+mine["prefix"] = pool[keep]
+side = rng.random(len(mine)) < 0.5
+bits = (np.uint64(1) << rng.integers(0, 4, len(mine)).astype(np.uint64))
+mine["in_mask"] = np.where(side, bits, 0).astype(np.uint64)
+mine["out_mask"] = np.where(side, 0, bits).astype(np.uint64)
+eng = _native.Engine(device=0)
+D.connect(eng, rank, world, transport="dir", path=os.environ["KR_COMM"])
+eng.set_params(25, 1, 2, max_bases=1000)
+# (A) the library's tree: csrc/h_comm.inc over the file transport
+eng.load_cands(mine)
+na = eng.cands_reduce(apply_filter=filt)
+eng.cands_bcast()
+a = eng.cands().copy()
+# (B) the reference tree of tests/dist_tree_reference.py over gloo, the merges on the same device
+dist.init_process_group("gloo", rank=rank, world_size=world)
+eng.load_cands(mine)
+nb = T.tree_reduce_candidates(eng, dist, rank, world, apply_filter=filt)
+T.broadcast_candidates(eng, dist, rank, world)
+b = eng.cands().copy()
+assert len(a) == len(b) and np.array_equal(a, b), (rank, len(a), len(b))
+if rank == 0:
+    assert na == nb == len(a) and 0 < len(a) < len(mine), (na, nb, len(a), len(mine))
+    print("TREES_AGREE", world, len(a))
+dist.barrier()
+dist.destroy_process_group()
+eng.comm_barrier()
+eng.close()
+'''
+
+
+@pytest.mark.parametrize("world,filt", [(2, True), (3, False), (5, True)])
+def test_library_tree_equals_the_gloo_reference_tree(world, filt, tmp_path):
+    """VERDICT r5 5b: the SAME per-rank candidate lists through kr_cands_reduce / kr_cands_bcast (csrc/h_comm.inc, file
+    transport, ranks sharing the GPU) and through tests/dist_tree_reference.py over gloo -- the executable statement of the
+    tree's semantics -- end in the same list on every rank, masks included (the two trees used to be tested apart)"""
+    import socket
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(TREE_WORKER)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), KR_ROOT=ROOT,
+                   KR_COMM=str(tmp_path / "comm"), KR_FILTER="1" if filt else "0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "TREES_AGREE" in outs[0], outs[0]
+
+
+def test_the_watchdog_aborts_a_communicator_whose_partner_never_answers(tmp_path):
+    """VERDICT r5 5a on the real transport: an RCCL communicator (world 1: the rank is its own silent partner), a receive
+    nobody sends to, the synchronisation an exchange round ends with.  The watchdog thread aborts the communicator when its
+    deadline passes; the call comes back with an error, later exchange calls are refused, the process lives.  In a child
+    process under a timeout: should the abort NOT unblock the call, the watchdog ends that process with status 124."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from krisp_amd import _native\n"
+        "eng = _native.Engine(device=0)\n"
+        "eng.comm_init(0, 1, _native.comm_unique_id())\n"
+        "eng.comm_set_timeout(3)\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    eng.debug_comm_hang()\n"
+        "    print('COMPLETED')\n"
+        "except _native.KrispHipError as e:\n"
+        "    print('RAISED', round(time.time() - t0, 1), e)\n"
+        "try:\n"
+        "    eng.cands_selfexchange()\n"
+        "except _native.KrispHipError as e:\n"
+        "    print('LATER', e)\n"
+        "eng.close()\n"
+        "print('ALIVE')\n")
+    p = subprocess.run(["timeout", "-k", "10", "90", sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "ALIVE" in out, out
+    assert "RAISED" in out, out                     # (by the watchdog's abort, or by RCCL refusing the unmatched receive)
+    if "aborting the communicator" in out:
+        assert "watchdog" in out.split("LATER", 1)[-1], out
+
+
 def test_a_failing_rank_stops_every_rank(tmp_path):
     """krisp_fasta over several ranks when ONE rank cannot read its genome: every rank exits with an
     error promptly (the failing rank with its own exception, the others with PeerFailed) instead of
@@ -760,6 +874,8 @@ def test_bench_starts_its_own_ranks_without_a_launcher(world, tmp_path):
     for n in (1, world):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--transport", "dir", "--steps", "2", "--warmup", "1",
                "--length", "2000000", "--no-cpu-baseline", "--lanes", "1", "--launch-timeout", "600"]
+        if n > 1:           # (the block a --gpus 8 run adds by itself: BASELINE configs[3]'s load timed in the same process)
+            cmd += ["--force-configs3", "--configs3-length", "3000000"]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         out = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -769,6 +885,11 @@ def test_bench_starts_its_own_ranks_without_a_launcher(world, tmp_path):
     assert many["n_gpus"] == world and many["rccl_ranks"] == 0 and one["rccl_ranks"] == 0
     assert many["scaling"] == "weak" and many["config"]["kmers_per_step"] > 0.95 * world * one["config"]["kmers_per_step"]
     assert "custom" in many["config"]["baseline_config"]
+    assert many["schema"] == 6 and many["roofline"]["scope"] == "step" and 0 < many["roofline"]["frac"] < 1
+    assert one["configs3"] is None
+    c3 = many["configs3"]
+    assert c3 and "error" not in c3 and c3["n_gpus"] == world and c3["value"] > 0, c3
+    assert 0.9 * world * 4 * 2 * 3e6 < c3["kmers_per_step"] <= world * 4 * 2 * 3e6
     # nothing of the launch is left behind (rendezvous files, message directories, the launcher's scratch)
     assert [p for p in os.listdir(tmp_path) if p.startswith(("krisp_comm", "krisp_bench_launch"))] == []
 

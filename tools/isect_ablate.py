@@ -1,5 +1,5 @@
 """Where k_intersect's time goes (4 x 50 Mbp, 25/1/2).  The ablation switches exist only in a -DKR_ABLATE build:
-    bash tools/ab_build.sh ablate -DKR_ABLATE
+    bash tools/ab_build.sh ablate -DKR_ABLATE -DKR_EXPERIMENTS
     KRISP_HIP_LIB=$PWD/krisp_amd/variants/ablate.so python tools/isect_ablate.py"""
 import sys
 
