@@ -141,6 +141,14 @@ int     kr_genome_free(kr_ctx*, int genome_id);
  * disjoint (skipped when D == 0, krisp_fasta.py:265).  Returns #candidates. */
 int64_t kr_intersect(kr_ctx*, const int* genome_ids, int n, const uint8_t* is_ingroup,
                      int apply_filter);
+/* DNA and RNA genomes in ONE run.  The reference compares k-mers as text, and an RNA genome's are written with U
+ * (kstream.py:481-508, 599): 'T' never equals 'U'.  The device alphabet has one code for both, so after this call (on != 0)
+ * the diagnostic filter of every call of this context runs in its mode 2 -- a column also passes when its ingroup and
+ * outgroup sets share nothing but that code (a superset of the reference's survivors, monotone like the filter itself) --
+ * and the host layer, which knows each genome's alphabet, drops the (left,right) pairs that hold the code (no DNA genome
+ * and RNA genome share such a pair as text) and decides the passed columns from the survivors' records
+ * (krisp_amd/krisp_fasta.py: _mixed_prefix_filter, _mixed_finish).  Any time. */
+int     kr_set_mixed_alphabets(kr_ctx*, int on);
 int64_t kr_cands_count(kr_ctx*);
 int64_t kr_cands_fetch(kr_ctx*, kr_cand* out, size_t cap);
 /* Replace the candidate set (sorted by prefix, unique). */
@@ -211,8 +219,8 @@ int64_t kr_fetch(kr_ctx*, kr_record* out, size_t cap);
  * windows lie; the host cuts the text of those windows out of the genomes it already holds.
  * Replaces, for such geometries, the same calls as kr_genome_sort + kr_intersect + kr_collect:
  * extractSortedKmers + mergeFiles + filterAlignments (krisp_fasta.py:237-272). */
-#define KR_WIDE_MAX_K 256
-#define KR_WIDE_MAX_FLANK 64
+#define KR_WIDE_MAX_K 1024
+#define KR_WIDE_MAX_FLANK 256
 /* one member window of a surviving group: cand = the group's number (its rank in (left,right) order
  * under KR_OPT_WIDE_ORDERED = 1; else any number, the same for all members of a group),
  * genome = index into the genome_ids of kr_wide_run, pos = base offset of the window in the

@@ -18,8 +18,8 @@ CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
 WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS, WIDE_SLOT_BITS, WIDE_NGROUPS = 0, 1, 2, 3, 4, 5, 6
-WIDE_MAX_K = 256
-WIDE_MAX_FLANK = 64
+WIDE_MAX_K = 1024
+WIDE_MAX_FLANK = 256
 COMM_ID_BYTES = 128
 
 SOFT_MAP, SOFT_OMIT = 0, 1
@@ -121,6 +121,7 @@ SYMBOLS = [
     ("kr_text_free", None, [_P]),
     ("kr_debug_isect", _c.c_int, [_P, _P]),
     ("kr_debug_lazy", _c.c_int, [_P, _P]),
+    ("kr_set_mixed_alphabets", _c.c_int, [_P, _c.c_int]),
     ("kr_build_experiments", _c.c_int, []),
     ("kr_comm_set_timeout", _c.c_int, [_P, _c.c_int]),
     ("kr_debug_comm_hang", _c.c_int, [_P]),
@@ -398,6 +399,10 @@ class Engine:
         self._check(self.lib.kr_set_params(self.ctx, L, D, R, SOFT_OMIT if omit_soft else SOFT_MAP,
                                            max_bases), "kr_set_params")
         self.params = (L, D, R)
+
+    def set_mixed_alphabets(self, on=True):
+        """DNA and RNA genomes in one run: the filter in its mode 2 (kr_set_mixed_alphabets)"""
+        self._check(self.lib.kr_set_mixed_alphabets(self.ctx, 1 if on else 0), "kr_set_mixed_alphabets")
 
     def set_strands(self, mode):
         """STRANDS_BOTH (complements), STRANDS_FORWARD, STRANDS_CANONICAL (kstream canonicals)"""

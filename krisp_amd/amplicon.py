@@ -168,6 +168,8 @@ class WindowGroups:
     def render_text(self, ingroup_labels, dot=False):
         """-> (csv, alignment) through the library, or None when it leaves a group to the general path"""
         from . import _native
+        if self.rna:
+            return None         # (the reference's renderer dies on the first column that holds U: the general path reproduces that)
         distinct = sorted(set(self.labels))
         rank = {t: i for i, t in enumerate(distinct)}
         label_of = np.array([rank[t] for t in self.labels], dtype=np.uint32)
@@ -254,6 +256,39 @@ def groups_from_records(records, labels, L, D, R, rna=False):
     return groups
 
 
+def groups_from_records_mixed(records, labels, L, D, R, rna_genomes):
+    """groups_from_records for a run that mixes DNA and RNA genomes (kstream.py:481-508, 599: an RNA genome's k-mers are
+    written with U): a record's text carries its genome's letter for code 3, so one key may be two sequences -- '..T..'
+    with the DNA genomes' labels, '..U..' with the RNA genomes' -- as the reference's text files hold them.  The result
+    sets of such runs are small (only (left,right) pairs free of T / U are in every genome): a plain loop."""
+    if len(records) == 0:
+        return []
+    records = _ordered_records(records, labels)
+    pm = codec.prefix_mask(L, R)
+    k = L + D + R
+    text = codec.keys_to_matrix(records["key"], L, D, R, False).tobytes().decode("ascii")
+    groups, last_pre = [], None
+    for row, (key, g, cnt) in enumerate(zip(records["key"].tolist(), records["genome"].tolist(), records["count"].tolist())):
+        s = text[row * k:(row + 1) * k]
+        if rna_genomes[g]:
+            s = s.replace("T", "U")
+        pre = key & int(pm)
+        if pre != last_pre:
+            groups.append([])
+            last_pre = pre
+        left, diag, right = s[:L], s[L + R:], s[L:L + R]
+        for a in groups[-1]:
+            if a.diag == diag and a.left == left and a.right == right:
+                a.labels.extend([labels[g]] * cnt)
+                break
+        else:
+            groups[-1].append(Amplicon(left, diag, right, [labels[g]] * cnt))
+    for grp in groups:
+        for a in grp:
+            a.labels.sort()
+    return groups
+
+
 def diagnostic_columns(group):
     """Amplicon.py:483-493: columns where the group's sequences differ."""
     return [i for i, col in enumerate(zip(*[a.diag for a in group])) if len(set(col)) > 1]
@@ -282,7 +317,9 @@ def bracket_line(group, ingroup):
     return "".join(br)
 
 
-_NOT_PLAIN = {ord(c): None for c in "ACGTU"}      # str.translate table: what is left is not a plain base
+# str.translate table: what is left is not a plain base.  'U' is NOT plain: the reference's consensus table is Biopython's
+# DNA table (Amplicon.py:10-12), a column holding U has no entry there and its renderer dies on it (see render below)
+_NOT_PLAIN = {ord(c): None for c in "ACGT"}
 
 
 def collapse_to_iupac(seqs):
@@ -330,6 +367,16 @@ def render_alignment(group, ingroup, dot):
 
 
 CSV_HEADER = "left_seq,diag_seq,right_seq"      # outputAlignments.py:26-31
+# The reference renders in a worker process that buffers PRINT_BLOCK groups between writes (outputAlignments.py:66-99;
+# krisp_fasta.py:284-290 passes print_block=1000).  A group whose consensus has no entry in its IUPAC table -- a column
+# holding 'U' (every RNA run: the table is the DNA one), or a lone ambiguity letter -- raises KeyError there
+# (Amplicon.py:65): the worker dies with a traceback, the blocks written so far stay, the rest is lost, the command exits 0.
+# Reproduced as it is (cores = 1): same bytes in the files, the notice on stderr.
+PRINT_BLOCK = 1000
+
+
+class RendererStopped(KeyError):
+    pass
 
 
 def render(groups, ingroup_labels, dot=False):
@@ -348,28 +395,38 @@ def render(groups, ingroup_labels, dot=False):
     gc.disable()
     try:
         brackets = {}
-        for g in groups:
-            if ingroup is None and len(g) == 1:
-                # the bulk of a large result (conserved regions, no outgroup): one sequence, no
-                # variable column -- the same text as the general path below, without its calls
-                a = g[0]
-                seq = a.left + a.diag + a.right
-                line = seq + " : " + a.label_string()
-                if dot:
-                    blocks.append(line + "\n\n")
-                else:
-                    shape = (len(a.left), len(a.diag))
-                    br = brackets.get(shape)
-                    if br is None:
-                        br = brackets[shape] = " " * (shape[0] - 1) + "{" + "-" * shape[1] + "}"
-                    blocks.append(line + "\n" + br + "\n\n")
-                if not seq.translate(_NOT_PLAIN):
-                    csv.append(a.left + "," + a.diag + "," + a.right)
-                else:
-                    csv.append(render_csv_row(g, ingroup))
-                continue
-            blocks.append(render_alignment(g, ingroup, dot) + "\n")
-            csv.append(render_csv_row(g, ingroup))
+        for gi_, g in enumerate(groups):
+          try:
+                if ingroup is None and len(g) == 1:
+                    # the bulk of a large result (conserved regions, no outgroup): one sequence, no
+                    # variable column -- the same text as the general path below, without its calls
+                    a = g[0]
+                    seq = a.left + a.diag + a.right
+                    line = seq + " : " + a.label_string()
+                    if dot:
+                        blocks.append(line + "\n\n")
+                    else:
+                        shape = (len(a.left), len(a.diag))
+                        br = brackets.get(shape)
+                        if br is None:
+                            br = brackets[shape] = " " * (shape[0] - 1) + "{" + "-" * shape[1] + "}"
+                        blocks.append(line + "\n" + br + "\n\n")
+                    if not seq.translate(_NOT_PLAIN):
+                        csv.append(a.left + "," + a.diag + "," + a.right)
+                    else:
+                        csv.append(render_csv_row(g, ingroup))
+                    continue
+                blocks.append(render_alignment(g, ingroup, dot) + "\n")
+                csv.append(render_csv_row(g, ingroup))
+          except KeyError as e:
+            import sys
+            kept = gi_ // PRINT_BLOCK * PRINT_BLOCK
+            print(f"krisp_fasta: the reference's renderer stops at group {gi_ + 1} (KeyError: {e.args[0]!r} has no IUPAC "
+                  f"consensus letter, Amplicon.py:65); as there, the {kept} groups of the blocks already written stay and "
+                  f"the rest is lost", file=sys.stderr)
+            del csv[1 + kept:]
+            del blocks[kept:]
+            break
     finally:
         if gc_was_on:
             gc.enable()

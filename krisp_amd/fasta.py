@@ -26,6 +26,9 @@ for _ch in b"ACGTNacgtn\n":
     _PLAIN[_ch] = True
 
 
+# texts the device's reader (kr_genome_upload_text) takes; KRISP_DEVICE_TEXT_MAX: tests force the host-parse fallback
+DEVICE_TEXT_MAX = int(os.environ.get("KRISP_DEVICE_TEXT_MAX", (1 << 32) - 64))
+
 # per file: the stage times of the last kr_ingest_file (read / inflate / parse), for the stage tables
 LAST_TIMINGS = {}
 
@@ -168,6 +171,14 @@ def ingest_on_device(eng, gid, text, universal, k, omit_soft):
     """text of a sequence file -> genome gid of `eng`, parsed on the device with the reference reader's semantics
     (kr_genome_upload_text; the host never sees the bases unless the genome holds characters outside ACGTNacgtn:
     then they come back for the side channel of ingest()).  Returns (bases on the device, is_rna, IUPAC k-mers)."""
+    if len(text) >= DEVICE_TEXT_MAX:
+        # the device's reader indexes its text with 32 bits: a longer text (a genome of more than 4.29e9 bases: the packed
+        # path takes them up to 2^33) is parsed by the library's host parser, same result (tests compare the two)
+        from . import _native
+        bases, _nrec, nspecial, rna, _fasta = _native.fasta_to_bases(text, universal, one_shot=True)
+        eng.upload(gid, bases)
+        special = scan_special(bases, k, omit_soft) if nspecial else []
+        return len(bases), bool(rna), special
     n, _nrec, nspecial, rna, _fasta = eng.upload_text(gid, text, universal, one_shot=True)
     special = scan_special(eng.fetch_bases(gid, n), k, omit_soft) if nspecial else []
     return n, bool(rna), special
@@ -206,6 +217,48 @@ def detect_rna(records):
         if b"U" in s or b"u" in s:
             return True
     return None
+
+
+def sniff_rna(filename, chunk=1 << 16):
+    """detect_rna(read_records(filename)) without reading the file: the head of the (inflated) stream until the first record
+    that holds T / t or U / u is complete or says 'T' (kstream.py:481-508 decides on that record: T anywhere in it -> DNA,
+    else U -> RNA).  For the flows that must know every genome's alphabet before the first genome is on the device (the
+    streaming flow: a mixed DNA / RNA run sets the filter's mode first).  Reference reader semantics as read_records:
+    FASTA iff the first line holds '>', that line consumed."""
+    ext = os.path.splitext(filename)[1]
+    opener = gzip.open if ext == ".gz" else (bz2.open if ext == ".bz2" else open)
+    universal = ext not in (".gz", ".bz2")
+    with opener(filename, "rb") as f:
+        tail, first, fasta, saw_u = b"", True, False, False
+        while True:
+            buf = f.read(chunk)
+            data = tail + buf
+            if universal:
+                data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n") if not (buf and data.endswith(b"\r")) else data
+            lines = data.split(b"\n")
+            tail = lines.pop() if buf else b""
+            if universal and buf and tail.endswith(b"\r"):
+                pass                                    # (a lone CR at the chunk edge may be half of CRLF: stays in the tail)
+            for ln in lines:
+                if first:
+                    fasta = b">" in ln
+                    first = False
+                    continue                            # (consumed by the detection, kstream.py:450)
+                ln = ln.strip()
+                header = fasta and ln.startswith(b">")
+                if header or not fasta:
+                    if saw_u:                           # the record that held U ended without a T
+                        return True
+                    if header:
+                        continue
+                if b"T" in ln or b"t" in ln:
+                    return False
+                if b"U" in ln or b"u" in ln:
+                    if not fasta:
+                        return True                     # (one line = one record)
+                    saw_u = True
+            if not buf:
+                return True if saw_u else None
 
 
 def to_bases(records, rna=False):

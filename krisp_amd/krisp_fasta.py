@@ -69,6 +69,37 @@ def _to_rna(groups):
     return groups
 
 
+def _mixed_prefix_filter(eng, L, R):
+    """DNA and RNA genomes in one run: the reference compares text, and 'T' never equals 'U' (kstream.py:481-508, 599 writes
+    an RNA genome's k-mers with U; shared.py:321-347 merges on the (left,right) strings) -- a (left,right) pair that holds
+    code 3 is in no DNA genome AND RNA genome alike.  The device matched them (one code for both letters): those candidates
+    go.  Returns the number left (the list is replaced on the device when any went)."""
+    cands = eng.cands()
+    if not len(cands):
+        return 0
+    lr = L + R
+    top = np.uint64((~0 << (64 - 2 * lr)) & 0xFFFFFFFFFFFFFFFF) if lr < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    p = cands["prefix"]
+    threes = (p >> np.uint64(1)) & p & np.uint64(0x5555555555555555) & top
+    keep = threes == 0
+    if not keep.all():
+        cands = cands[keep]
+        eng.load_cands(cands)
+    return len(cands)
+
+
+def _mixed_finish(records, labels, geo, rna, ingroup_labels, do_filter):
+    """... and the exact filter on the survivors of the device's mode-2 filter (k_intersect.inc: passes_filter -- a column
+    whose ingroup and outgroup sets share nothing but code 3 passed there): here each genome's alphabet is known, the
+    groups are text, and the reference's own predicate decides (Amplicon.py:495-521 via filterAlignments.py:4-40)"""
+    Le, De, Re = geo
+    groups = amplicon.groups_from_records_mixed(records, labels, Le, De, Re, rna)
+    if do_filter and len(ingroup_labels):
+        ing = frozenset(ingroup_labels)
+        groups = [g for g in groups if amplicon.ingroup_unique_columns(g, ing)]
+    return groups
+
+
 def _check_geometry(L, D, R):
     """geometries of the packed path: the whole amplicon in one 64-bit key"""
     k = L + D + R
@@ -85,8 +116,8 @@ def _is_wide(L, D, R):
 
 
 def _check_wide(L, D, R):
-    """geometries of the wide path (kr_wide_run): flanks of up to WIDE_MAX_FLANK bases (one key each, or
-    ranked through two keys), amplicons of up to WIDE_MAX_K"""
+    """geometries of the wide path (kr_wide_run): flanks of up to WIDE_MAX_FLANK bases (one key each, or -- longer than 32
+    bases -- ranked piece by piece through up to eight keys), amplicons of up to WIDE_MAX_K"""
     from . import _native
     if not (1 <= L <= _native.WIDE_MAX_FLANK and 1 <= R <= _native.WIDE_MAX_FLANK and L + D + R <= _native.WIDE_MAX_K):
         raise UnsupportedGeometry(
@@ -99,7 +130,7 @@ for _a, _b in zip(b"ACGT", b"TGCA"):
     _COMP_U8[_a] = _b
 
 
-def _groups_from_hits(hits, texts, labels, L, D, R):
+def _groups_from_hits(hits, texts, labels, L, D, R, rna_genomes=None):
     """kr_wide_run hits (group, genome, position, strand) -> groups of amplicon.Amplicon in the
     reference's order: groups by (left,right), sequences by diag; the window text is cut from
     the genome the host already holds (soft-mask mapped, kstream.py:622-642; reverse
@@ -117,6 +148,8 @@ def _groups_from_hits(hits, texts, labels, L, D, R):
         W = t[sel["pos"].astype(np.int64)[:, None] + ar] & np.uint8(0xDF)
         rc = sel["strand"] == 1
         W[rc] = _COMP_U8[W[rc][:, ::-1]]
+        if rna_genomes is not None and rna_genomes[gi]:
+            W[W == ord("T")] = ord("U")                 # (an RNA genome's k-mers are written with U: kstream.py:599)
         # rows order as the reference's merged file does: (left, right) groups, sequences by diag inside
         # (the device's group numbers need not ascend with (left, right): KR_OPT_WIDE_ORDERED)
         row = np.empty((len(sel), k + 4), dtype=np.uint8)
@@ -351,6 +384,10 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
             stats["device_s"] = time.time() - t1
             if quirk_all_fail:
                 return [], stats
+            if stats.get("mixed_rna"):
+                groups = _mixed_finish(records, labels, (Le, De, Re), stats["mixed_rna"], ingroup_labels, do_filter)
+                stats["candidates"] = len(groups)
+                return groups, stats
             if not touched and not all_rna:
                 return amplicon.RecordGroups(records, labels, Le, De, Re), stats
             groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
@@ -414,11 +451,16 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
         t2 = time.time()
         del first
         t3 = time.time()
-        if any(rna) and not all(rna):
-            raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+        mixed = any(rna) and not all(rna)
+        if mixed:
+            if any(specials):
+                raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
+            eng.set_mixed_alphabets(True)
         finish = _to_rna if all(rna) else (lambda groups: groups)
         ids = list(range(len(files)))
         ncand = eng.intersect(ids, flags, apply_filter=do_filter and not quirk_all_fail)
+        if mixed and ncand:
+            ncand = _mixed_prefix_filter(eng, Le, Re)
         counts = [eng.count(i) for i in ids]
         t4 = time.time()
         if verbose:
@@ -437,6 +479,10 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
                          "collect": t5 - t4, "context freed": time.time() - t5}}
     if quirk_all_fail:
         return [], stats
+    if mixed:
+        groups = _mixed_finish(records, labels, (Le, De, Re), rna, ingroup_labels, do_filter)
+        stats["candidates"] = len(groups)
+        return groups, stats
     if not touched and not any(rna):
         return amplicon.RecordGroups(records, labels, Le, De, Re), stats
     groups = amplicon.groups_from_records(records, labels, Le, De, Re, rna=False)
@@ -578,6 +624,12 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
                 del futs[g]
             stats["batches"] += 1
 
+    # every genome's alphabet before the first batch (fasta.sniff_rna reads the head of a file): a run that mixes DNA and
+    # RNA genomes filters in mode 2 from the first batch on (kr_set_mixed_alphabets)
+    kinds = [bool(fasta.sniff_rna(f)) for f in files]
+    mixed = any(kinds) and not all(kinds)
+    if mixed:
+        eng.set_mixed_alphabets(True)
     running = [None]        # number of running candidates; the list itself stays on the device between the batches of pass 1
     eager = [True]          # (kr_genome_free does not touch it: no copy to the host and back per batch -- ADVICE r5)
     kept = []
@@ -603,9 +655,12 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
             kept.clear()
 
     run_pass(batch, True, pass1)
+    if mixed and running[0]:
+        running[0] = _mixed_prefix_filter(eng, Le, Re)
     final = eng.cands().copy() if running[0] else np.empty(0, dtype=_native.CAND)
-    if any(rna) and not all(rna):
-        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+    if mixed and any(sp for sp in specials if sp):
+        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
+    stats["mixed_rna"] = [bool(r) for r in rna] if mixed else None
     touched = {(l, r) for sp in specials for (l, d, r) in sp} if not quirk_all_fail else set()
     pure = sorted({_prefix_key(l, r) for (l, r) in touched if _pure(l) and _pure(r)})
     srecs = []
@@ -679,8 +734,9 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     texts = [b for b, _, _ in loaded]
     specials = [[codec.split_window(w, Le, De, Re) for w in sp] for _, _, sp in loaded]
     rna = [bool(r) for _, r, _ in loaded]
-    if any(rna) and not all(rna):
-        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
+    mixed = any(rna) and not all(rna)
+    if mixed and any(specials):
+        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
     finish = _to_rna if all(rna) else (lambda groups: groups)
     if len(files) == 1:
         # mergeFiles moves the lone k-mer file; its lines carry no label, so later stages
@@ -708,6 +764,8 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             ids = list(range(len(files)))
             for i, t in enumerate(texts):
                 eng.upload(i, t)
+            if mixed:
+                eng.set_mixed_alphabets(True)
             nhits = eng.wide_run(ids, flags, apply_filter=do_filter)
             hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
             ngroups = int(eng.wide_fetch(_native.WIDE_NGROUPS)[0])
@@ -715,7 +773,16 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             if verbose:
                 for f, cnt in zip(files, counts):
                     print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)
-            if touched:
+            if mixed:
+                # (text decides: flank pairs that hold T / U are in no DNA genome and RNA genome alike, and the filter's
+                # columns are compared letter by letter -- _mixed_finish's rule on member windows)
+                groups = _groups_from_hits(hits, texts, labels, Le, De, Re, rna_genomes=rna)
+                groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
+                if do_filter and ingroup_labels:
+                    groups = [g for g in groups if amplicon.ingroup_unique_columns(g, ingroup_labels)]
+                ngroups = len(groups)
+                finish = lambda g: g        # noqa: E731
+            elif touched:
                 groups = _groups_from_hits(hits, texts, labels, Le, De, Re)
                 sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text,
                                                (Le, De, Re), ingroup_labels, do_filter)
@@ -736,7 +803,11 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             eng.upload(i, t)
             eng.sort(i)
         ids = list(range(len(files)))
+        if mixed:
+            eng.set_mixed_alphabets(True)
         ncand = eng.intersect(ids, flags, apply_filter=do_filter and not quirk_all_fail)
+        if mixed and ncand:
+            ncand = _mixed_prefix_filter(eng, Le, Re)
         counts = [eng.count(i) for i in ids]
         if verbose:
             for f, c in zip(files, counts):
@@ -752,6 +823,10 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
                  candidates=int(ncand))
     if quirk_all_fail:
         return [], stats
+    if mixed:
+        groups = _mixed_finish(records, labels, (Le, De, Re), rna, ingroup_labels, do_filter)
+        stats["candidates"] = len(groups)
+        return groups, stats
     if not touched and not any(rna):
         # (plain records: the renderer works from them directly, the list of groups is built only if someone walks it)
         return amplicon.RecordGroups(records, labels, Le, De, Re), stats
@@ -1215,10 +1290,11 @@ def _merge_files_wide(contents, labels, L, D, R, device):
     from . import _native
     _check_wide(L, D, R)
     k = L + D + R
-    texts = []
+    texts, rnas = [], []
     for lines in contents:
         flat = b"".join(lines)
         rna = b"U" in flat and b"T" not in flat
+        rnas.append(rna)
         if flat.translate(None, b"ACGTU," if rna else b"ACGT,"):
             raise fasta.IupacWindowsUnsupported("k-mer files of amplicons longer than one key that hold IUPAC "
                                                 "ambiguity letters: use the fused flow (find_regions)")
@@ -1235,7 +1311,12 @@ def _merge_files_wide(contents, labels, L, D, R, device):
             eng.upload(i, t)
         nhits = eng.wide_run(ids, [True] * len(ids), apply_filter=False)
         hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
-    return _groups_from_hits(hits, texts, labels, L, D, R)
+    # (an RNA genome's file holds U: its lines come back with U; a (left,right) pair that holds T / U is text no DNA file and
+    # RNA file share -- shared.py:321-347 merges on the strings)
+    groups = _groups_from_hits(hits, texts, labels, L, D, R, rna_genomes=rnas if any(rnas) else None)
+    if any(rnas) and not all(rnas):
+        groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
+    return groups
 
 
 def _parse_merged(path):
@@ -1339,9 +1420,11 @@ def build_parser():
                                 prog="krisp", formatter_class=argparse.RawTextHelpFormatter,
                                 epilog="Limits of the GPU path, none of which the reference has (it works on text of any length;\n"
                                        "kstream.py:617-642) -- each is refused with a message, never answered wrongly:\n"
-                                       "  * a sequence file of 2^32 bases or more (4.29 Gbp; positions are 32 bits on the device);\n"
-                                       "  * amplicons longer than 32 bases (or more than 16 diagnostic bases): conserved flanks of 1 .. 64\n"
-                                       "    bases each, amplicons of at most 256.\n"
+                                       "  * a sequence file of 2^33 bases or more (8.6 Gbp: the sorted k-mers of one such genome are what one GPU's\n"
+                                       "    memory holds at all); with amplicons longer than 32 bases, 2^32 bases;\n"
+                                       "  * amplicons longer than 32 bases (or more than 16 diagnostic bases): conserved flanks of 1 .. 256\n"
+                                       "    bases each, amplicons of at most 1024;\n"
+                                       "  * DNA and RNA genomes in one run together with IUPAC ambiguity letters, or over several ranks.\n"
                                        "A genome set that does not fit the GPU's memory sorted at once goes through it in batches\n"
                                        "(same result; KRISP_STREAM_BATCH=n forces batches of n genomes).")
     p.add_argument("files", nargs="+", type=str, metavar="PATH", help="Fasta file to read. .gz, .bz2")

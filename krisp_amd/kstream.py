@@ -117,7 +117,7 @@ class kstream:
         by line order, and the key holds the fields in that order (kr_set_field_order; the krisp_fasta order (first,
         last, middle) keeps its own layout and kernels) -- or unsorted (stream order: the device's k-mers in window
         order, the host's special windows placed among them by position; several k record by record).  k > 32: the krisp_fasta
-        combination through the wide path (flanks <= 64, k <= 256).
+        combination through the wide path (flanks <= 256, k <= 1024).
         The device carries windows of plain ACGT (upper case only when lower case is kept or omitted); a window holding
         anything else that the chain would keep -- IUPAC letters, lower case under 'neither', other characters -- runs
         through the reference's chain on the host by itself and joins the sorted stream.
@@ -125,7 +125,7 @@ class kstream:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
             formed before the filters);
           * more than two split points;
-          * k > 32 outside the krisp_fasta combination or without --sort, flanks > 64, k > 256;
+          * k > 32 outside the krisp_fasta combination or without --sort, flanks > 256, k > 1024;
           * a custom column order on an input large enough to need key-space slices (> 2^28 bases: decided at run time)."""
         self.plan_reason = None
         if self.kmers is None or len(self.kmers) < 1:

@@ -420,6 +420,9 @@ def render_alignment(group, ingroup, dot):
     return "\n".join(text)
 
 
+PRINT_BLOCK = 1000          # krisp_fasta.py:288
+
+
 def render_output(lines, ingroup, dot, tag="merged_file"):
     """outputAlignments.py:101-162 at cores=1 -> (csv_text, align_text).  `tag`
     labels lines that carry none (a single input genome: the result file is
@@ -427,9 +430,20 @@ def render_output(lines, ingroup, dot, tag="merged_file"):
     groups = read_groups(lines, tag)
     csv = ["left_seq,diag_seq,right_seq"]
     aln = []
-    for g in groups:
-        aln.append(render_alignment(g, ingroup, dot))
-        csv.append(render_csv_row(g, ingroup))
+    for i, g in enumerate(groups):
+        try:
+            a = render_alignment(g, ingroup, dot)
+            c = render_csv_row(g, ingroup)
+        except KeyError:
+            # outputAlignments.py:66-99: the worker process that renders buffers print_block groups between writes
+            # (krisp_fasta.py:284-290: 1000); a consensus column without an entry in the IUPAC table (Amplicon.py:65 -- 'U',
+            # a lone ambiguity letter) raises there, the worker dies, what it had not written yet is lost, main() exits 0
+            kept = i // PRINT_BLOCK * PRINT_BLOCK
+            del csv[1 + kept:]
+            del aln[kept:]
+            break
+        aln.append(a)
+        csv.append(c)
     return "\n".join(csv) + "\n", "".join(a + "\n" for a in aln)
 
 

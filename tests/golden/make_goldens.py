@@ -359,8 +359,16 @@ def canon_lines(path):
     return sorted(lines)
 
 
+def _maybe_hashed(lines, hash_big):
+    """canonicalised lines as they are, or -- long amplicons: megabytes of text -- their count and the sha256 of
+    '\\n'.join(lines) (tests/ compare through the same function)"""
+    if hash_big and sum(len(x) + 1 for x in lines) > 65536:
+        return {"lines": len(lines), "sha256": sha("\n".join(lines).encode())}
+    return lines
+
+
 def run_fasta_case(name, files, ingroup, outgroup, L, D, R, omit=False, dot=False,
-                   keep_sorted=False, main_args=None, run_main=True):
+                   keep_sorted=False, main_args=None, run_main=True, hash_big=False):
     """files: {filename: bytes}.  Runs stages (for intermediates) and main()
     (for the final text), both with cores=1."""
     k = L + D + R
@@ -391,11 +399,11 @@ def run_fasta_case(name, files, ingroup, outgroup, L, D, R, omit=False, dot=Fals
         out["sorted"] = sorted_info
         merged = f"{work}/merged_file.txt"
         mergeFiles(list(kfiles), merged, 1, work, False)
-        out["merged_canon"] = canon_lines(merged)
+        out["merged_canon"] = _maybe_hashed(canon_lines(merged), hash_big)
         if k > L + R:
             filt = f"{work}/filtered.txt"
             filterAlignments(merged, filt, frozenset(simplename(f) for f in ingroup))
-            out["filtered_canon"] = canon_lines(filt)
+            out["filtered_canon"] = _maybe_hashed(canon_lines(filt), hash_big)
         if not run_main:
             # the reference's renderer dies with KeyError when a column holds a
             # lone IUPAC letter (Amplicon.py:65); only the stages are pinned
@@ -551,7 +559,104 @@ def fasta_cases():
     return cases
 
 
+def fasta_cases_r6():
+    """round 6 (VERDICT r5 'lift the input limits'): runs that mix DNA and RNA genomes, flanks longer than 64 bases,
+    amplicons longer than 256 -- what the earlier builds refused and the reference simply runs"""
+    cases = []
+    rng = random.Random(20261005)
+
+    def family(n, glen, rate, L, D, R, nrec=3, plants_per_rec=3, t_frac=0.25):
+        k = L + D + R
+        w = [(1 - t_frac) / 3] * 3 + [t_frac]
+        anc = ["".join(rng.choices("ACGT", weights=w, k=glen // nrec)) for _ in range(nrec)]
+        plants = []
+        for r in range(nrec):
+            for _ in range(plants_per_rec):
+                pos = rng.randrange(k, len(anc[r]) - k)
+                b1, b2 = rng.sample("ACGT", 2)
+                plants.append((r, pos, b1, b2))
+        return anc, plants
+
+    def genome(anc, plants, rate, ingroup, rna, extra=None):
+        recs = []
+        for r, s in enumerate(anc):
+            m = list(mutate(rng, s, rate))
+            for (pr, pos, b1, b2) in plants + (extra or []):
+                if pr == r:
+                    m[pos] = b1 if ingroup else b2
+            a = rng.randrange(0, max(1, len(m) - 40))
+            for j in range(a, min(len(m), a + rng.randint(0, 20))):
+                m[j] = m[j].lower()
+            if rng.random() < 0.5:
+                m[rng.randrange(len(m))] = "N"
+            recs.append("".join(m))
+        text = fasta_text(recs)
+        if rna:
+            text = text.replace(b"T", b"U").replace(b"t", b"u")
+        return text
+
+    # ---- DNA + RNA genomes in one run
+    for name, kinds_in, kinds_out, (L, D, R), glen, rate, tf in [
+            ("mixed_in_dna_out_rna_6_1_3", [False, False], [True, True], (6, 1, 3), 900, 0.01, 0.25),
+            ("mixed_both_sides_8_2_4", [False, True], [False, True], (8, 2, 4), 1200, 0.01, 0.15),
+            ("mixed_in_rna_out_dna_5_1_5", [True, True], [False], (5, 1, 5), 800, 0.02, 0.25),
+            ("mixed_no_outgroup_7_1_3", [False, True, False], [], (7, 1, 3), 700, 0.01, 0.2),
+            ("mixed_wide_20_10_20", [False, True], [True], (20, 10, 20), 1800, 0.003, 0.02),
+            ("mixed_wide_in_dna_out_rna_18_6_18", [False, False], [True, True], (18, 6, 18), 1800, 0.003, 0.03),
+            ("all_rna_6_1_3", [True, True], [True], (6, 1, 3), 600, 0.01, 0.25),
+    ]:
+        anc, plants = family(len(kinds_in) + len(kinds_out), glen, rate, L, D, R, t_frac=tf)
+        # (a column that is T in every ingroup genome and T / U in every outgroup genome: diagnostic to the reference only
+        # when the sides' alphabets differ -- it compares letters)
+        extra = []
+        for r in range(len(anc)):
+            pos = rng.randrange(L + D + R, len(anc[r]) - (L + D + R))
+            extra.append((r, pos, "T", "T"))
+        files, ing, outg = {}, [], []
+        for i, rna in enumerate(kinds_in):
+            fn = f"in{i}.fa"
+            files[fn] = genome(anc, plants, rate, True, rna, extra)
+            ing.append(fn)
+        for i, rna in enumerate(kinds_out):
+            fn = f"out{i}.fasta"
+            files[fn] = genome(anc, plants, rate, False, rna, extra)
+            outg.append(fn)
+        c = run_fasta_case(name, files, ing, outg, L, D, R)
+        c["files"] = {fn: v.decode() for fn, v in files.items()}
+        cases.append(c)
+    # ---- flanks longer than 64 bases, amplicons longer than 256
+    for name, n_in, n_out, (L, D, R), glen, rate, omit in [
+            ("long_70_10_70", 2, 2, (70, 10, 70), 2400, 0.0015, False),
+            ("long_100_5_90", 2, 1, (100, 5, 90), 2400, 0.001, False),
+            ("long_40_220_40", 2, 2, (40, 220, 40), 2700, 0.001, False),
+            ("long_65_1_2", 1, 2, (65, 1, 2), 1800, 0.002, True),
+            ("long_130_60_129", 2, 2, (130, 60, 129), 3000, 0.0007, False),
+    ]:
+        anc, plants = family(n_in + n_out, glen, rate, L, D, R, plants_per_rec=4)
+        files, ing, outg = {}, [], []
+        for i in range(n_in):
+            fn = f"in{i}.fa"
+            files[fn] = genome(anc, plants, rate, True, False)
+            ing.append(fn)
+        for i in range(n_out):
+            fn = f"out{i}.fasta"
+            files[fn] = genome(anc, plants, rate, False, False)
+            outg.append(fn)
+        c = run_fasta_case(name, files, ing, outg, L, D, R, omit=omit, hash_big=True)
+        c["files"] = {fn: v.decode() for fn, v in files.items()}
+        cases.append(c)
+    return cases
+
+
 def main():
+    if "--r6-only" in sys.argv:
+        fc = fasta_cases_r6()
+        with open(HERE / "fasta_cases_r6.json", "w") as f:
+            json.dump(fc, f, indent=1)
+        for c in fc:
+            print(c["name"], "merged", len(c["merged_canon"]), "filtered",
+                  len(c.get("filtered_canon", [])), "csv bytes", len(c.get("csv", "")))
+        return
     kr = kstream_cases_routes()
     with open(HERE / "kstream_cases_routes.json", "w") as f:
         json.dump(kr, f, indent=1)
@@ -572,6 +677,10 @@ def main():
     with open(HERE / "fasta_cases.json", "w") as f:
         json.dump(fc, f, indent=1)
     print(f"krisp_fasta cases: {len(fc)}")
+    fc6 = fasta_cases_r6()
+    with open(HERE / "fasta_cases_r6.json", "w") as f:
+        json.dump(fc6, f, indent=1)
+    fc = fc + fc6
     for c in fc:
         print(c["name"], "merged", len(c["merged_canon"]), "filtered",
               len(c.get("filtered_canon", [])), "csv bytes", len(c.get("csv", "")))
