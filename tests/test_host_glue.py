@@ -178,7 +178,7 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     assert p["layout"] == "custom" and p["order"] == [2, 1, 0]
     for change, why in ((dict(allow="ACG"), "closed under complement"), (dict(disallow="A"), "closed under complement"),
                         (dict(kmers=40, split=[30, -2], complements=False), "outside the krisp_fasta combination"),
-                        (dict(kmers=300, split=[30, -2]), "k > 256"), (dict(kmers=120, split=[70, -2]), "flanks outside"),
+                        (dict(kmers=1100, split=[30, -2]), "k > 1024"), (dict(kmers=620, split=[270, -2]), "flanks outside"),
                         (dict(kmers=40, split=[30, -2], sort=False), "k > 32 without --sort")):
         ks = kstream(**dict(base, **change))
         assert ks.device_plan() is None and why in ks.plan_reason, (change, ks.plan_reason)
