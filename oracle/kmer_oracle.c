@@ -70,8 +70,22 @@ static void radix_sort_u64(uint64_t* a, uint64_t* tmp, size_t n, int lowbit) {
 /* Both-strand keys of every surviving window, sorted.  mode 0 = map soft mask
  * to upper case (krisp_fasta default), 1 = omit windows that are not
  * str.isupper().  Returns the count, or a negative KRO_ERR_*. */
+static int64_t sorted_keys_impl(const uint8_t* bases, size_t n, int L, int D, int R, int mode, int topbits, uint64_t topval,
+                                uint64_t* out, size_t cap);
 int64_t kro_sorted_keys(const uint8_t* bases, size_t n, int L, int D, int R, int mode,
                         uint64_t* out, size_t cap) {
+    return sorted_keys_impl(bases, n, L, D, R, mode, 0, 0, out, cap);
+}
+/* ... restricted to ONE key-space slice: the keys whose top `topbits` bits equal topval (the first topbits / 2 bases of
+ * `left`).  What a full-size check of a human-scale genome can afford on the host: a 3 Gbp genome has 6e9 keys, one of
+ * its 256 slices 2.3e7 (tests/test_gpu_fullsize.py compares that slice with the device's, bit for bit). */
+int64_t kro_sorted_keys_slice(const uint8_t* bases, size_t n, int L, int D, int R, int mode, int topbits, uint64_t topval,
+                              uint64_t* out, size_t cap) {
+    if (topbits < 0 || topbits > 32 || (topbits & 1)) return KRO_ERR_PARAM;
+    return sorted_keys_impl(bases, n, L, D, R, mode, topbits, topval, out, cap);
+}
+static int64_t sorted_keys_impl(const uint8_t* bases, size_t n, int L, int D, int R, int mode, int topbits, uint64_t topval,
+                                uint64_t* out, size_t cap) {
     const int k = L + D + R;
     if (k < 1 || k > 32 || L < 0 || D < 0 || R < 0) return KRO_ERR_PARAM;
     const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -104,7 +118,9 @@ int64_t kro_sorted_keys(const uint8_t* bases, size_t n, int L, int D, int R, int
             uint64_t left = (D + R >= 32) ? 0 : (w >> (2 * (D + R)));
             uint64_t diag = (w >> (2 * R)) & dmask, right = w & rmask;
             uint64_t key = ((D + R >= 32) ? 0 : (left << (2 * (D + R)))) | (right << (2 * D)) | diag;
-            out[m++] = (k == 32) ? key : (key << (64 - 2 * k));
+            key = (k == 32) ? key : (key << (64 - 2 * k));
+            if (topbits && (key >> (64 - topbits)) != topval) continue;
+            out[m++] = key;
         }
     }
     if (m > 1) {

@@ -56,6 +56,21 @@ def sorted_keys(bases, L, D, R, omit=False):
     return out[:n].copy()
 
 
+def sorted_keys_slice(bases, L, D, R, topbits, topval, omit=False, cap=None):
+    """the sorted keys whose top `topbits` bits equal topval (kro_sorted_keys_slice): one key-space slice of a genome"""
+    buf = np.frombuffer(bases, dtype=np.uint8)
+    if cap is None:
+        cap = max(1024, int(2 * len(buf) / (1 << topbits) * 1.5) + 65536)
+    out = np.empty(cap, dtype=np.uint64)
+    fn = lib().kro_sorted_keys_slice
+    fn.restype = ctypes.c_int64
+    n = fn(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(buf)), L, D, R, 1 if omit else 0,
+           ctypes.c_int(topbits), ctypes.c_uint64(topval), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
+    if n < 0:
+        raise OracleError(ERRORS.get(n, str(n)))
+    return out[:n].copy()
+
+
 def _ptrs(key_arrays):
     n = len(key_arrays)
     arr = (ctypes.c_void_p * n)(*[k.ctypes.data for k in key_arrays])

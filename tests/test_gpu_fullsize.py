@@ -215,7 +215,38 @@ def test_c5_three_gbp_genomes():
     c1, info = _run(fam, 28, 1, 2, light=True)
     assert info["nslices"] == 64        # 6e9 keys per genome -> slices of <= 1.05e8 keys
     assert len(c1) > 10_000_000
-    print(f"\nC5: {len(c1)} candidates; generation {t1 - t0:.0f} s, device + checks {time.time() - t1:.0f} s; {info}")
+    t2 = time.time()
+    _check_last_slice_against_the_oracle(fam, 28, 1, 2, 64)
+    print(f"\nC5: {len(c1)} candidates; generation {t1 - t0:.0f} s, device + checks {t2 - t1:.0f} s, "
+          f"last slice of both genomes == oracle {time.time() - t2:.0f} s; {info}")
+
+
+def _check_last_slice_against_the_oracle(fam, L, D, R, nslices):
+    """an oracle check a human-scale genome can afford -- oracle/kmer_oracle.c restricted to ONE key-space
+    slice (generate every key of the genome record by record on host threads, keep those of the slice, sort) against the
+    device's sorted keys of that slice (kr_debug_fetch selector 5: the slice sorted last), bit for bit, for every genome.
+    The slice is the last one (all-ones slice digits: TT.. lefts); 1 / nslices of the 6e9 keys each."""
+    from concurrent.futures import ThreadPoolExecutor
+    from krisp_amd import _native
+    from oracle import kmer_oracle as K
+    K.build()
+    topbits = (nslices - 1).bit_length()
+    with _native.Engine() as eng:
+        eng.set_params(L, D, R, max_bases=max(len(t) for _, _, t in fam))
+        assert eng.debug_info()["nslices"] == nslices
+        for i, (_, _, t) in enumerate(fam):
+            eng.upload(i, t)
+            eng.sort(i)
+            n = eng.count(i)
+            got = eng.debug_fetch(i, 5, int(n / nslices * 1.5) + 65536)     # relative keys of the last slice
+            got = (np.uint64(nslices - 1) << np.uint64(64 - topbits)) | (got >> np.uint64(topbits))
+            recs = bytes(t).split(b"\n")
+            with ThreadPoolExecutor(max_workers=min(16, len(recs))) as pool:          # (ctypes releases the GIL)
+                parts = list(pool.map(lambda r: K.sorted_keys_slice(r, L, D, R, topbits, nslices - 1), recs))
+            want = np.sort(np.concatenate(parts))
+            assert len(got) == len(want) > n / nslices / 2, (i, len(got), len(want))
+            assert np.array_equal(got, want), f"last slice of genome {i} differs from the oracle"
+            eng.free(i)
 
 
 @BIG

@@ -264,11 +264,13 @@ def test_options_are_checked(N, monkeypatch):
 
 
 def test_hard_limits_fail_loudly(N):
-    """the library's caps are errors with a message, never silent truncation: genomes of 2^32 bases,
+    """the library's caps are errors with a message, never silent truncation: genomes of 2^33 bases (2^32 on the wide path),
     more keys in one sort unit than a buffer descriptor spans, geometries beyond the key and mask formats"""
     with N.Engine() as e:
+        with pytest.raises(N.KrispHipError, match="2\\^33"):
+            e.set_params(25, 1, 2, max_bases=(1 << 33) - 10)     # (round 6: the packed path takes genomes below 2^33 bases)
         with pytest.raises(N.KrispHipError, match="2\\^32"):
-            e.set_params(25, 1, 2, max_bases=(1 << 32) - 10)
+            e.set_params_wide(30, 40, 30, max_bases=(1 << 32) - 10)
         with pytest.raises(N.KrispHipError):
             e.set_params(20, 1, 12, max_bases=1000)              # k = 33
         with pytest.raises(N.KrispHipError):
@@ -290,9 +292,11 @@ def test_hard_limits_fail_loudly(N):
         assert rc > 0 and e.intersect(list(range(33)), [True] * 33, apply_filter=False) == rc
     with N.Engine() as e:
         with pytest.raises(N.KrispHipError):
-            e.set_params_wide(65, 10, 20, max_bases=1000)        # flank > KR_WIDE_MAX_FLANK
+            e.set_params_wide(257, 10, 20, max_bases=1000)       # flank > KR_WIDE_MAX_FLANK (256: eight pieces of 32 bases)
         with pytest.raises(N.KrispHipError):
-            e.set_params_wide(30, 250, 30, max_bases=1000)       # amplicon > KR_WIDE_MAX_K
+            e.set_params_wide(30, 1000, 30, max_bases=1000)      # amplicon > KR_WIDE_MAX_K (1024)
+        e.set_params_wide(65, 10, 20, max_bases=1000)            # (what rounds 1-5 refused)
+        e.set_params_wide(30, 250, 30, max_bases=1000)
 
 
 def test_more_oversized_buckets_than_the_list_holds(N, K):
