@@ -241,6 +241,8 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
                                    (and KR_OPT_WIDE_ORDERED = 0) KR_WIDE_GROUPS lists one group of every mirror pair
                                    (a:b) / (b:a) only -- the two are decided alike -- and a hit of the unlisted one
                                    carries the listed one's number with bit 31 set */
+       KR_WIDE_BATCH_USED = 7,  /* u64 x 1: genomes per batch of the sort + intersect phases of the last run (0 = all at once): a genome set
+                                   whose sorted keys do not fit the device goes through the phases in batches (kr_wide_run) */
        KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
                                    one-sector slot table in the last run, 0 = looked up through index + sorted keys,
                                    255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0), 254 = not built: with L = R the

@@ -758,7 +758,8 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
         touched = {(l, r) for sp in specials for (l, d, r) in sp}
         probes = sorted(p for p in touched if _pure(p[0]) and _pure(p[1]))
         probe_text = np.frombuffer("\n".join(l + "A" * De + r for l, r in probes).encode(), dtype=np.uint8)
-        with _native.Engine(device=device) as eng:
+        budget = int(os.environ.get("KRISP_HBM_BUDGET", "0"))       # (bytes; tests and shared devices: kr_create's HBM budget)
+        with _native.Engine(device=device, hbm_budget=budget) as eng:
             eng.set_params_wide(Le, De, Re, omit_soft=omit_soft,
                                 max_bases=max(max(len(t) for t in texts), len(probe_text)))
             ids = list(range(len(files)))
@@ -770,6 +771,7 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
             hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
             ngroups = int(eng.wide_fetch(_native.WIDE_NGROUPS)[0])
             counts = eng.wide_fetch(_native.WIDE_COUNTS).tolist()
+            stats["wide_batch"] = int(eng.wide_fetch(_native.WIDE_BATCH_USED)[0])       # (0: every genome sorted at once)
             if verbose:
                 for f, cnt in zip(files, counts):
                     print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)

@@ -396,7 +396,9 @@ nh = eng.wide_run(mine, [fam[g][1] for g in mine], apply_filter=filt)
 if rank == 0:
     hits = eng.wide_fetch(_native.WIDE_HITS)
     got = amplicon.merged_lines(KF._groups_from_hits(hits, texts, names, L, Dg, R))
-    with _native.Engine(device=0) as one:            # the same genomes on one GPU, no communicator
+    if os.environ.get("KR_WIDE_BATCH"):
+        assert int(eng.wide_fetch(_native.WIDE_BATCH_USED)[0]) == int(os.environ.pop("KR_WIDE_BATCH"))
+    with _native.Engine(device=0) as one:            # the same genomes on one GPU, no communicator, all at once
         one.set_params_wide(L, Dg, R, max_bases=max(len(t) for t in texts))
         for g, t in enumerate(texts):
             one.upload(g, t)
@@ -411,7 +413,8 @@ eng.close()
 
 
 @pytest.mark.parametrize("world,geo,filt", [(2, (30, 40, 30), True), (3, (30, 40, 30), True), (3, (40, 20, 36), True),
-                                            (2, (20, 30, 20), False), (5, (32, 60, 32), True)])
+                                            (2, (20, 30, 20), False), (5, (32, 60, 32), True), (2, (30, 40, 30), "batch1"),
+                                            (2, (70, 12, 40), "batch2")])
 def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
     """kr_wide_run with a communicator: 6 genomes of 1.5 Mbp (0.3 Mbp without the filter) sharded over `world` ranks (sharing cuda:0,
     file transport): the flank spectra and the group list are intersected over the ranks by the tree
@@ -427,6 +430,8 @@ def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), KR_ROOT=ROOT,
                    KR_COMM=str(tmp_path / "comm"), KR_L=str(geo[0]), KR_D=str(geo[1]), KR_R=str(geo[2]),
                    KR_FILTER="1" if filt else "0")
+        if isinstance(filt, str):           # (round 6: every rank's phases in batches of so many of ITS genomes)
+            env["KR_WIDE_BATCH"] = filt[5:]
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=900)[0] for p in procs]
@@ -1164,6 +1169,70 @@ def test_streaming_flow_equals_the_in_core_flow(case, tmp_path, monkeypatch):
     got, stats = KF.find_regions(ing, outg, L, R, k)
     assert stats["streamed"] and 1 <= stats["batch"] < 6, stats
     assert _render_groups(got, labels) == want_text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo", [(30, 40, 30), (20, 30, 20), (40, 12, 36), (70, 10, 66)])
+def test_wide_path_in_batches_equals_the_in_core_run(geo, tmp_path, monkeypatch):
+    """round 6: amplicons longer than one key for a genome set whose sorted keys do not fit the device at
+    once -- the sort + intersect phases of kr_wide_run take the genomes in batches (the dictionary of a phase is a running
+    intersection: first batch intersected, later batches probed), forced with KR_WIDE_BATCH = 1, 2, 4 and reached by
+    itself under an HBM budget the one-shot run does not fit (the library halves the batch until the run fits); the groups
+    and the text are the in-core run's, byte for byte.  Six genomes with N runs, lower case, a duplicated region."""
+    import numpy as np
+    from krisp_amd import krisp_fasta as KF
+    L, D, R = geo
+    k = L + D + R
+    rng = np.random.default_rng(sum(geo))
+    G = 240_000
+    anc = rng.integers(0, 4, size=G)
+    anc[7000:7400] = anc[1000:1400]
+    snps = rng.choice(np.arange(200, G - 200), size=80, replace=False)
+    files = []
+    for gi in range(6):
+        g = anc.copy()
+        at = rng.integers(0, G, size=40)
+        g[at] = (g[at] + 1 + rng.integers(0, 3, size=40)) % 4
+        is_in = gi < 3
+        g[snps] = (anc[snps] + (1 if is_in else 2)) % 4
+        s = bytearray(np.frombuffer(b"ACGT", dtype=np.uint8)[g].tobytes())
+        a = int(rng.integers(0, G - 400))
+        s[a:a + 150] = bytes(s[a:a + 150]).lower()
+        b = int(rng.integers(0, G - 400))
+        s[b:b + 30] = b"N" * 30
+        p = tmp_path / f"{'in' if is_in else 'out'}{gi}.fa"
+        t = bytes(s)
+        p.write_bytes(b">a\n" + b"\n".join(t[i:i + 80] for i in range(0, G // 2, 80)) + b"\n>b x\n" + t[G // 2:] + b"\n")
+        files.append(str(p))
+    ing, outg = files[:3], files[3:]
+    labels = [KF.simplename(f) for f in ing]
+    for v in ("KR_WIDE_BATCH", "KRISP_HBM_BUDGET"):
+        monkeypatch.delenv(v, raising=False)
+    want, wstats = KF.find_regions(ing, outg, L, R, k)
+    assert wstats["wide_batch"] == 0 and len(want) >= 10
+    want_text = _render_groups(want, labels)
+    for batch in ("1", "2", "4"):
+        monkeypatch.setenv("KR_WIDE_BATCH", batch)
+        got, stats = KF.find_regions(ing, outg, L, R, k)
+        assert stats["wide_batch"] == int(batch) and stats["candidates"] == wstats["candidates"] and stats["kmers"] == wstats["kmers"]
+        assert _render_groups(got, labels) == want_text, (geo, batch)
+    monkeypatch.delenv("KR_WIDE_BATCH")
+    # budgets from roomy to tight: somewhere the one-shot run stops fitting and the library goes on in batches by itself
+    from krisp_amd import _native
+    streamed = []
+    for mb in list(range(400, 120, -20)) + list(range(120, 4, -3)):
+        monkeypatch.setenv("KRISP_HBM_BUDGET", str(mb << 20))
+        try:
+            got, stats = KF.find_regions(ing, outg, L, R, k)
+        except _native.KrispHipError as e:
+            # (too tight for this attempt -- or for what follows the run: the windows' rows --: refused, never wrong; a
+            # tighter budget may still do, the run then goes in batches and holds less when the rows are cut)
+            assert e.code == _native.ERR_CAPACITY, e
+            continue
+        assert _render_groups(got, labels) == want_text, (geo, mb)
+        if stats["wide_batch"]:
+            streamed.append((mb, stats["wide_batch"]))
+    assert streamed, "no budget made the run go on in batches"
 
 
 @pytest.mark.gpu
