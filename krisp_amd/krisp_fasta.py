@@ -978,20 +978,84 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
                 wg = _merge_groups(wg, touched_w, sg)
             return (_to_rna(wg) if all_rna else wg), stats
 
+        # Round 6: a rank whose shard does not fit its GPU sorted at once takes it in batches, as
+        # find_regions does on one GPU (_find_regions_streaming): the first batch intersected, later batches probed, the
+        # batch freed; the exchange of the candidate lists is the same; the records are then collected batch by batch in a
+        # second pass over the shard and travel to rank 0 as bytes (kr_comm_allgather) instead of from the device buffer of
+        # ONE kr_collect.  KRISP_STREAM_BATCH=n forces batches of n genomes per rank (tests).
+        bases_of = {g: b for g, (b, _, _) in zip(mine, loaded)}
+        flag_of = {g: labels[g] in ingroup_labels for g in mine}
+        batched = [None]
+
+        def shard_batches():
+            B = batched[0]
+            both = any(flag_of.values()) and not all(flag_of.values()) and filt
+            at, first = 0, True
+            while at < len(mine):
+                m = max(B, 2) if (first and both) else B        # (the first batch holds both sides: nothing prunes else)
+                yield mine[at:at + m]
+                at, first = at + m, False
+
         def device_part():
             eng.set_params(Le, De, Re, omit_soft=omit_soft, max_bases=int(kinds[2]))
-            for g, (bases, _, _) in zip(mine, loaded):
-                eng.upload(g, bases)
-                eng.sort(g)
-            eng.intersect(mine, [labels[g] in ingroup_labels for g in mine], apply_filter=filt)    # safe local pruning
-            return sum(eng.count(g) for g in mine)
+            batched[0] = _plan_batch(eng, len(mine), int(kinds[2])) if len(mine) > 1 else None
+            if batched[0] is None:
+                for g in mine:
+                    eng.upload(g, bases_of[g])
+                    eng.sort(g)
+                eng.intersect(mine, [flag_of[g] for g in mine], apply_filter=filt)    # safe local pruning
+                return sum(eng.count(g) for g in mine)
+            total, running = 0, None
+            for ids_b in shard_batches():
+                for g in ids_b:
+                    eng.upload(g, bases_of[g])
+                    eng.sort(g)
+                fl = [flag_of[g] for g in ids_b]
+                running = eng.intersect(ids_b, fl, apply_filter=filt) if running is None else \
+                    eng.probe_cands(ids_b, fl, apply_filter=filt)
+                total += sum(eng.count(g) for g in ids_b)
+                for g in ids_b:
+                    eng.free(g)
+            return total
+
+        def collect_shard():
+            """this rank's records of the candidates now on the device -> numpy (batched shards: a pass over the batches)"""
+            cands = eng.cands().copy()
+            parts = []
+            for ids_b in shard_batches():
+                for g in ids_b:
+                    eng.upload(g, bases_of[g])
+                    eng.sort(g)
+                eng.load_cands(cands)
+                if len(cands):
+                    parts.append(eng.collect(ids_b))
+                for g in ids_b:
+                    eng.free(g)
+            return np.concatenate(parts) if parts else np.empty(0, dtype=_native.RECORD)
+
+        def gather_host_records(recs):
+            """every rank's record array -> rank 0 (None elsewhere), as bytes through kr_comm_allgather"""
+            got = eng.comm_allgather(np.ascontiguousarray(recs).tobytes())
+            if rank != 0:
+                return None
+            parts = [np.frombuffer(b, dtype=_native.RECORD) for b in got if len(b)]
+            return np.concatenate(parts) if parts else np.empty(0, dtype=_native.RECORD)
 
         counts = together(device_part)
+        # (every rank learns whether ANY rank took its shard in batches: the records then travel as bytes on all of them)
+        any_batched = eng.comm_allreduce([1.0 if batched[0] is not None else 0.0], "max")[0] > 0
+        if any_batched and batched[0] is None:
+            batched[0] = len(mine)
         ncand = eng.cands_reduce(apply_filter=filt)
         eng.cands_bcast()
-        nrec = together(lambda: 0 if quirk_all_fail else eng.collect(mine, fetch=False))
-        total = eng.records_gather() if not quirk_all_fail else 0
-        allrec = eng.fetch_records(total) if rank == 0 and not quirk_all_fail else None
+        if any_batched:
+            myrec = together(lambda: np.empty(0, dtype=_native.RECORD) if quirk_all_fail else collect_shard())
+            nrec = len(myrec)
+            allrec = gather_host_records(myrec) if not quirk_all_fail else None
+        else:
+            nrec = together(lambda: 0 if quirk_all_fail else eng.collect(mine, fetch=False))
+            total = eng.records_gather() if not quirk_all_fail else 0
+            allrec = eng.fetch_records(total) if rank == 0 and not quirk_all_fail else None
         sprec, touched = None, set()
         if specials_all is not None and not quirk_all_fail:
             # the ACGT members of every (left,right) group an IUPAC window touches: each rank looks them up in ITS
@@ -1005,10 +1069,12 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
                 cands = np.zeros(len(pure), dtype=_native.CAND)
                 cands["prefix"] = np.array(pure, dtype=np.uint64)
                 eng.load_cands(cands)
-                return eng.collect(mine, fetch=False)
+                return collect_shard() if any_batched else eng.collect(mine, fetch=False)
 
-            together(special_lookups)
-            if pure:
+            sp_local = together(special_lookups)
+            if pure and any_batched:
+                sprec = gather_host_records(sp_local)
+            elif pure:
                 tot2 = eng.records_gather()
                 sprec = eng.fetch_records(tot2) if rank == 0 else None
         eng.comm_barrier()

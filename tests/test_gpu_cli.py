@@ -736,6 +736,15 @@ def test_iupac_letters_and_rna_over_several_ranks(seed, tmp_path):
     devices = [0] * (2 if seed % 2 == 0 else 3)
     groups, _ = KF.find_regions_multi_device(ing, outg, L, R, k, devices)
     assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
+    if seed % 4 == 0 and L + D + R <= 32:
+        # (round 6: every rank takes its shard in batches of one genome -- the special windows' look-ups in batches, too)
+        import os as _os
+        _os.environ["KRISP_STREAM_BATCH"] = "1"
+        try:
+            groups, _ = KF.find_regions_multi_device(ing, outg, L, R, k, [0, 0])
+        finally:
+            del _os.environ["KRISP_STREAM_BATCH"]
+        assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
 
 
 @pytest.mark.parametrize("name,texts,n_in", [
@@ -848,13 +857,18 @@ def test_kstream_command_line_as_documented(tmp_path):
     assert out2.returncode == 0 and outp.read_bytes() == out.stdout
 
 
-@pytest.mark.parametrize("world,name", [(2, "c1_25_1_2"), (3, "c1_25_1_2"), (2, "c1_30_40_30"), (3, "rand9_20_10_20")])
+@pytest.mark.parametrize("world,name", [(2, "c1_25_1_2"), (3, "c1_25_1_2"), (2, "c1_30_40_30"), (3, "rand9_20_10_20"),
+                                        (2, "c1_25_1_2+batch1"), (2, "rand12_8_1_4+batch2"), (3, "rand12_8_1_4+batch1"),
+                                        (2, "c1_30_40_30+wbatch1")])
 def test_krisp_fasta_command_line_over_several_ranks(world, name, tmp_path):
     """python -m torch.distributed.run ... -m krisp_amd.krisp_fasta: genomes sharded over the ranks
     (here sharing the one GPU: the file transport of the library's exchange), candidate tree reduction,
     records gathered to rank 0 -- the output is the reference's, byte for byte"""
     import subprocess
     import sys
+    # (round 6: "+batchN" = every rank takes ITS shard in batches of N genomes -- KRISP_STREAM_BATCH --, "+wbatchN" = the wide
+    # path's phases in batches -- KR_WIDE_BATCH: shards beyond one GPU's memory)
+    name, _, how = name.partition("+")
     case = [c for c in FC if c["name"] == name][0]
     paths = _paths(case, tmp_path)
     aln = str(tmp_path / "a.txt")
@@ -864,6 +878,10 @@ def test_krisp_fasta_command_line_over_several_ranks(world, name, tmp_path):
     cmd += [paths[f] for f in case["ingroup"]] + ["--outgroup"] + [paths[f] for f in case["outgroup"]]
     cmd += case["main_args"] + ["--out_align", aln, "--out_csv", csvp]
     env = dict(os.environ, KRISP_COMM_TRANSPORT="dir", KRISP_COMM_FILE=str(tmp_path / "comm"))
+    if how.startswith("batch"):
+        env["KRISP_STREAM_BATCH"] = how[5:]
+    elif how.startswith("wbatch"):
+        env["KR_WIDE_BATCH"] = how[6:]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert open(csvp).read() == case["csv"]
