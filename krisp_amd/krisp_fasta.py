@@ -1358,32 +1358,48 @@ def _merge_files_wide(contents, labels, L, D, R, device):
     from . import _native
     _check_wide(L, D, R)
     k = L + D + R
-    texts, rnas = [], []
+    texts, rnas, specials = [], [], []
     for lines in contents:
         flat = b"".join(lines)
         rna = b"U" in flat and b"T" not in flat
         rnas.append(rna)
-        if flat.translate(None, b"ACGTU," if rna else b"ACGT,"):
-            raise fasta.IupacWindowsUnsupported("k-mer files of amplicons longer than one key that hold IUPAC "
-                                                "ambiguity letters: use the fused flow (find_regions)")
+        plain = b"ACGU," if rna else b"ACGT,"
+        if flat.translate(None, plain):
+            # lines that hold IUPAC ambiguity letters (the reference keeps such k-mers: kstream.py:11-18, Amplicon.py:298-348
+            # reads them like any line): they stay text -- the groups they touch are rebuilt on the host from them and from
+            # the plain members the device finds for their (left,right) pairs, as find_regions does (round 6: refused before)
+            sp = [ln for ln in lines if ln.translate(None, plain)]
+            lines = [ln for ln in lines if not ln.translate(None, plain)]
+            specials.append([tuple(x.decode() for x in ln.split(b",")) for ln in sp])
+        else:
+            specials.append([])
         rec = [ln.replace(b",", b"") for ln in lines]
         if any(len(r) != k for r in rec):
             raise ValueError("k-mer file with lines of different lengths")
         t = b"\n".join(rec)
         texts.append(np.frombuffer(t.replace(b"U", b"T") if rna else t, dtype=np.uint8))
     ids = list(range(len(texts)))
+    mixed = any(rnas) and not all(rnas)
+    if any(specials) and any(rnas):
+        raise MixedAlphabet("k-mer files of RNA genomes that hold IUPAC letters, amplicons longer than one key")
+    touched = {(l, r) for sp in specials for (l, d, r) in sp}
+    probes = sorted(p for p in touched if _pure(p[0]) and _pure(p[1]))
+    probe_text = np.frombuffer("\n".join(l + "A" * D + r for l, r in probes).encode(), dtype=np.uint8)
     with _native.Engine(device=device) as eng:
-        eng.set_params_wide(L, D, R, omit_soft=False, max_bases=max(1, max(len(t) for t in texts)))
+        eng.set_params_wide(L, D, R, omit_soft=False, max_bases=max(1, max(len(t) for t in texts), len(probe_text)))
         eng.set_strands(_native.STRANDS_FORWARD)
         for i, t in enumerate(texts):
             eng.upload(i, t)
         nhits = eng.wide_run(ids, [True] * len(ids), apply_filter=False)
         hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
-    # (an RNA genome's file holds U: its lines come back with U; a (left,right) pair that holds T / U is text no DNA file and
-    # RNA file share -- shared.py:321-347 merges on the strings)
-    groups = _groups_from_hits(hits, texts, labels, L, D, R, rna_genomes=rnas if any(rnas) else None)
-    if any(rnas) and not all(rnas):
-        groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
+        # (an RNA genome's file holds U: its lines come back with U; a (left,right) pair that holds T / U is text no DNA file
+        # and RNA file share -- shared.py:321-347 merges on the strings)
+        groups = _groups_from_hits(hits, texts, labels, L, D, R, rna_genomes=rnas if any(rnas) else None)
+        if mixed:
+            groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
+        if touched:
+            sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, (L, D, R), frozenset(), False)
+            groups = _merge_groups(groups, touched, sgroups)
     return groups
 
 

@@ -645,6 +645,26 @@ def fasta_cases_r6():
         c = run_fasta_case(name, files, ing, outg, L, D, R, omit=omit, hash_big=True)
         c["files"] = {fn: v.decode() for fn, v in files.items()}
         cases.append(c)
+    # ---- amplicons longer than one key whose k-mer files hold IUPAC ambiguity letters (kept by the reference, kstream.py:11-18):
+    # the stage functions on such files (VERDICT r5 missing #6).  The renderer dies on a lone ambiguity letter: stages only.
+    for name, n_in, n_out, (L, D, R), glen, rate in [
+            ("long_iupac_20_10_20", 2, 2, (20, 10, 20), 900, 0.004),
+            ("long_iupac_40_4_33", 2, 1, (40, 4, 33), 1200, 0.002),
+    ]:
+        anc, plants = family(n_in + n_out, glen, rate, L, D, R)
+        files, ing, outg = {}, [], []
+        for i in range(n_in + n_out):
+            text = genome(anc, plants, rate, i < n_in, False).decode()
+            m = list(text)
+            body = [j for j, ch in enumerate(m) if ch in "ACGT"]
+            for j in rng.sample(body, 4):
+                m[j] = rng.choice("RYKMSW")
+            fn = f"in{i}.fa" if i < n_in else f"out{i - n_in}.fasta"
+            files[fn] = "".join(m).encode()
+            (ing if i < n_in else outg).append(fn)
+        c = run_fasta_case(name, files, ing, outg, L, D, R, hash_big=True, run_main=False)
+        c["files"] = {fn: v.decode() for fn, v in files.items()}
+        cases.append(c)
     return cases
 
 

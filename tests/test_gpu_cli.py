@@ -111,7 +111,7 @@ def test_wide_amplicons_match_reference_intermediates(case, tmp_path):
                                     case["L"], case["R"], _amplicon(case), omit_soft=case["omit_soft"])
     want = case["filtered_canon"] if "filtered_canon" in case else case["merged_canon"]
     assert canon_equal(sorted(amplicon.merged_lines(groups)), want)
-    if "filtered_canon" in case and canon_lines(case["merged_canon"]) is not None and not case["name"].startswith("mixed"):
+    if "filtered_canon" in case and canon_lines(case["merged_canon"]) is not None and not case["name"].startswith(("mixed", "long_iupac")):     # (the device's count leaves out what the host decides: mixed alphabets, groups touched by IUPAC windows)
         assert stats["candidates"] == len({tuple(ln.split(",")[0:3:2]) for ln in case["merged_canon"]})
     assert stats["kmers"] == sum(case["sorted"][f]["lines"] for f in case["ingroup"] + case["outgroup"])
 
