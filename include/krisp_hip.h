@@ -402,8 +402,9 @@ const char* kr_debug_copy_which(kr_ctx*);
  * 1 KR_ABLATE, 2 I3_ABL, 3 P2_ABL, 4 LS2_NORANK, 5 KR_EXP_NOLOOKUP: csrc/k_keys.inc).  No context, no GPU needed. */
 int     kr_build_experiments(void);
 /* KR_OPT_LAZY_ORDER's counters: out[0] LDS sorts of whole slices kr_genome_sort left out, [1] made later (anchor, fetch, probe),
- * [2] kr_collect calls that sorted only the buckets their candidates touch, [3] the option's value */
-int     kr_debug_lazy(kr_ctx*, int64_t* out4);
+ * [2] kr_collect calls that read only the buckets their candidates touch, [3] the option's value, [4] intersection launches whose
+ * anchor genome stayed in bucket order as well (k_intersect3t<., UA>), [5] 1 unless KR_FUSE_ANCHOR=0, [6..7] 0 */
+int     kr_debug_lazy(kr_ctx*, int64_t* out8);
 int     kr_debug_isect(kr_ctx*, int64_t* out8);
 /* the latest placement search of the pass-1 output buffers: out8[0] candidates probed, [1] buffers handed to the sort lanes,
  * [2..5] probe milliseconds of the four fastest candidates, [6] the median, [7] the slowest (bench.py prints them: which

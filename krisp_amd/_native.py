@@ -630,9 +630,10 @@ class Engine:
     def debug_lazy(self):
         """KR_OPT_LAZY_ORDER's counters (kr_debug_lazy): LDS sorts of whole slices the sorts left out, made later, collects
         that sorted the touched buckets only, the option's value"""
-        o = np.zeros(4, dtype=np.int64)
+        o = np.zeros(8, dtype=np.int64)
         self.lib.kr_debug_lazy(self.ctx, _ptr(o))
-        return dict(skipped=int(o[0]), ordered_later=int(o[1]), touch_collects=int(o[2]), on=int(o[3]))
+        return dict(skipped=int(o[0]), ordered_later=int(o[1]), touch_collects=int(o[2]), on=int(o[3]),
+                    anchor_in_bucket_order=int(o[4]), fuse_anchor=int(o[5]))
 
     def copy_gbps(self, nbytes=1 << 30, reps=10):
         v = self.lib.kr_debug_copy_gbps(self.ctx, nbytes, reps)
