@@ -92,6 +92,27 @@ def field_layout_ok(widths, order):
     return False
 
 
+def merge_fields(fields, order):
+    """the window's fields (widths, line order) in key order `order`, with neighbouring fields that stay neighbours and in
+    order fused into blocks: (block widths in line order, their key order) -- what kr_set_field_order takes when the blocks
+    are at most three --, or None.  Empty fields join the block in front of them."""
+    live = [f for f in order if fields[f] > 0]
+    runs = []                                   # maximal runs f, f + 1, ... (over the non-empty fields) inside `live`
+    nonempty = [f for f in range(len(fields)) if fields[f] > 0]
+    nxt = {a: b for a, b in zip(nonempty, nonempty[1:])}
+    for f in live:
+        if runs and nxt.get(runs[-1][-1]) == f:
+            runs[-1].append(f)
+        else:
+            runs.append([f])
+    if len(runs) > 3:
+        return None
+    by_line = sorted(range(len(runs)), key=lambda i: runs[i][0])          # blocks in line order
+    widths = [sum(fields[f] for f in runs[i]) for i in by_line]
+    rank = {i: j for j, i in enumerate(by_line)}
+    return widths, [rank[i] for i in range(len(runs))]
+
+
 def keys_to_ordered_fields_bytes(keys, fields, order, rna=False):
     """keys that hold the window's fields in `order` (kr_set_field_order; the krisp_fasta layout is order 0 2 1) -> bytes
     of the sorted output: the fields in LINE order (widths `fields`, empty ones included) joined by ','."""

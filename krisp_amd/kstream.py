@@ -124,7 +124,8 @@ class kstream:
         Not on the device, with the reason in `plan_reason`:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
             formed before the filters);
-          * more than two split points;
+          * two or more split points counted from the end (the line's columns then leave window order), or a custom
+            column order that cuts the window into more than three blocks;
           * k > 32 outside the krisp_fasta combination or without --sort, flanks > 256, k > 1024;
           * a custom column order on an input large enough to need key-space slices (> 2^28 bases: decided at run time)."""
         self.plan_reason = None
@@ -168,18 +169,20 @@ class kstream:
         if self.split is None:
             fields = [k]
         else:
-            if len(self.split) not in (1, 2):
-                return self._no_plan("more than two split points")
-            a = self.split[0]
-            if a < 0 or a > k:
-                return self._no_plan("split point outside the k-mer")
-            if len(self.split) == 1:
-                fields = [a, k - a]
-            else:
-                b = self.split[1]
-                if b > 0 or a - b > k:
-                    return self._no_plan("split points outside the k-mer")
-                fields = [a, 0, k - a] if b == 0 else [a, k - a + b, -b]     # kstream.py:824-830
+            # kstream.py:805-832: the sizes are taken in turn -- a size >= 0 cuts that many characters off the FRONT of what
+            # is left, a negative one off its END --, the line is front parts + what is left + end parts, the end parts in
+            # the order they were cut.  Any number of sizes (round 6: two at most before) whose parts come out in WINDOW
+            # order: at most one of them negative (a second end part would stand behind the first in the line, in front
+            # of it in the window).  -0 is 0: an empty front part (kstream.py:824-830).
+            head, tail, left = [], [], k
+            for z in self.split:
+                if (z >= 0 and z > left) or (z < 0 and -z > left):
+                    return self._no_plan("split point outside the k-mer")
+                (head if z >= 0 else tail).append(abs(z))
+                left -= abs(z)
+            if len(tail) > 1:
+                return self._no_plan("two or more split points counted from the end: the line's columns leave window order")
+            fields = head + [left] + tail
         common = dict(k=k, fields=fields, strands=strands, allow=allow_bases, keepcase=keepcase, expand=self.expandiupac)
         if self.sort is False:
             if k > 32:
@@ -216,8 +219,9 @@ class kstream:
         else:
             layout, geometry = "custom", (k, 0, 0)
             order = live + [c for c in range(len(fields)) if c not in live]
-            if not codec.field_layout_ok(fields, order):
-                return self._no_plan("no key layout holds this column order")      # (none known: every permutation of three fields has one)
+            merged = codec.merge_fields(fields, order)
+            if merged is None or not codec.field_layout_ok(*merged):
+                return self._no_plan("this column order cuts the window into more than three blocks: no key layout holds it")
         # (--expand-iupac: windows holding N are dropped before the expansion -- the disallow / allow test above --, so an
         # expansion is the handful of combinations of a window's other ambiguity letters)
         return dict(common, layout=layout, order=order, geometry=geometry, sorted=True)
@@ -341,7 +345,8 @@ class kstream:
                     # first bases of `left`, which a custom layout moves away from the top of the key)
                     self.plan_reason = "a custom column order on an input that needs key-space slices"
                     return None
-                eng.set_field_order(fields + [0] * (3 - len(fields)), order + list(range(len(fields), 3)))
+                mf, mo = codec.merge_fields(fields, order)      # (neighbouring columns that stay neighbours are one block of the key)
+                eng.set_field_order(mf + [0] * (3 - len(mf)), mo + list(range(len(mf), 3)))
             if plan["strands"]:
                 eng.set_strands(plan["strands"])
             if allow is not None:

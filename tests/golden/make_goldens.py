@@ -350,6 +350,66 @@ def kstream_cases_routes():
     return cases
 
 
+def kstream_cases_r6():
+    """round 6 (VERDICT r5 missing #5): split lists of any length (kstream.py:805-832 takes any) -- sorted in line order, by
+    column lists that cut the window into at most three blocks (device) or more (host chain), unsorted, with several k --
+    and the sets that stay on the host chain (two sizes counted from the end).  Written to kstream_cases_r6.json."""
+    cases = []
+
+    def add(name, kwargs, seqs=None, file_text=None, fname="in.fa", use_write=False):
+        res = run_kstream(kwargs, seqs, file_text, fname, use_write)
+        cases.append({"name": name, "kwargs": kwargs, "seqs": seqs,
+                      "file_text": file_text, "fname": fname,
+                      "use_write": use_write, **res})
+
+    rng = random.Random(606)
+    plain = "ACGT" * 12 + "acgt" * 3 + "Nn"
+    iupac = "ACGT" * 14 + "acgt" * 2 + "Nn" + "RYKMSWry"
+
+    def fasta(alphabet, nrec, lo, hi):
+        recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))) for _ in range(nrec)]
+        return "".join(f">rec{j} d\n{s}\n" for j, s in enumerate(recs))
+
+    texts = [fasta(plain, 3, 10, 40), fasta(iupac, 4, 10, 40), fasta(plain, 2, 24, 50),
+             fasta(iupac, 3, 12, 40).replace("T", "U").replace("t", "u")]
+    strands = [("comp", dict(complements=True)), ("canon", dict(canonicals=True)), ("fwd", {})]
+    softs = [("map", dict(mapsoft=True)), ("omit", dict(omitsoft=True)), ("keep", {})]
+    n = 0
+    for k, split, collists in [
+            (9, [2, 3, -2], [None, [0], [3], [2, 3], [3, 0], [1, 2], [0, 1, 2, 3], [3, 2], [1, 3], [2, 0]]),
+            (8, [1, 2, 3], [None, [3], [1, 2], [2, 3, 0], [3, 1]]),
+            (8, [2, -3, 1], [None, [3], [1], [2, 3]]),
+            (9, [2, 2, 2, -2], [None, [4], [3, 4], [1, 2, 3], [4, 0, 1], [2, 0]]),
+            (7, [-2], [None, [1], [1, 0]]),
+            (7, [-3, 2], [None, [2], [1, 2], [2, 0]]),
+            (8, [0, 3, -0], [None, [2], [3, 1]]),
+            (8, [3, -2, -1], [None, [3], [2, 3]]),              # two sizes from the end: host chain
+            (8, [8, 0, -0], [None]),
+    ]:
+        for cols in collists:
+            sname, skw = strands[n % 3]
+            mname, mkw = softs[(n // 3) % 3]
+            kw = dict(kmers=k, disallow="Nn", sort=True, split=split, **skw, **mkw)
+            if cols is not None:
+                kw["sortcols"] = cols
+            add(f"msplit{n}_{sname}_{mname}_{split}_{cols}", kw, file_text=texts[n % len(texts)],
+                fname=f"m{n % len(texts)}.fa", use_write=bool((n // 2) % 2))
+            n += 1
+    # unsorted streams and several k
+    for j, (k, split) in enumerate([(9, [2, 3, -2]), (8, [1, 2, 3]), (7, [-2]), (9, [2, 2, 2, -2]), (8, [3, -2, -1])]):
+        sname, skw = strands[j % 3]
+        mname, mkw = softs[(j + 1) % 3]
+        add(f"msplit_unsorted{j}_{sname}_{mname}_{split}", dict(kmers=k, disallow="Nn", split=split, **skw, **mkw),
+            file_text=texts[j % len(texts)], fname="u.fa", use_write=bool(j % 2))
+    add("msplit_multik_sorted", dict(kmers=[7, 9], complements=True, disallow="Nn", mapsoft=True, sort=True, split=[2, 2, -2],
+                                     sortcols=[2, 3]), file_text=texts[0], fname="k.fa")
+    add("msplit_multik_unsorted", dict(kmers=[6, 8], disallow="Nn", omitsoft=True, split=[1, 2, -1]), file_text=texts[2], fname="k.fa")
+    add("msplit_expand", dict(kmers=8, complements=True, disallow="Nn", mapsoft=True, sort=True, expandiupac=True, split=[2, 2, -2],
+                              sortcols=[3, 0]), file_text=texts[1], fname="e.fa")
+    add("msplit_allow", dict(kmers=8, allow="ACGT", sort=True, split=[3, 2, -1], sortcols=[2]), file_text=texts[1], fname="a.fa")
+    return cases
+
+
 # --------------------------------------------------------------------------
 # 2. krisp_fasta-level cases (stages + final text)
 # --------------------------------------------------------------------------
@@ -669,6 +729,12 @@ def fasta_cases_r6():
 
 
 def main():
+    if "--ks6-only" in sys.argv:
+        k6 = kstream_cases_r6()
+        with open(HERE / "kstream_cases_r6.json", "w") as f:
+            json.dump(k6, f, indent=1)
+        print(f"kstream cases (round 6): {len(k6)}; raised: {sorted(c['name'] for c in k6 if 'raises' in c)}")
+        return
     if "--r6-only" in sys.argv:
         fc = fasta_cases_r6()
         with open(HERE / "fasta_cases_r6.json", "w") as f:
@@ -677,6 +743,9 @@ def main():
             print(c["name"], "merged", len(c["merged_canon"]), "filtered",
                   len(c.get("filtered_canon", [])), "csv bytes", len(c.get("csv", "")))
         return
+    k6 = kstream_cases_r6()
+    with open(HERE / "kstream_cases_r6.json", "w") as f:
+        json.dump(k6, f, indent=1)
     kr = kstream_cases_routes()
     with open(HERE / "kstream_cases_routes.json", "w") as f:
         json.dump(kr, f, indent=1)

@@ -213,7 +213,8 @@ def _geo(kwargs):
 
 
 KS_MORE = json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json"))) + \
-    json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json")))
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json"))) + \
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_r6.json")))
 
 
 @pytest.mark.parametrize("case", [c for c in KS + KS_MORE if _geo(c["kwargs"]) is not None],

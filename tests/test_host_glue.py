@@ -61,7 +61,8 @@ def test_kstream_host_chain_on_the_device_served_combinations(case, tmp_path):
     assert list(ks.host_lines(src)) == case["out"]
 
 
-KS_ROUTES = json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json")))
+KS_ROUTES = json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json"))) + \
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_r6.json")))          # (round 6: split lists of any length)
 
 
 @pytest.mark.parametrize("case", KS_ROUTES, ids=lambda c: c["name"])

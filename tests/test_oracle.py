@@ -12,7 +12,8 @@ from oracle import krisp_oracle as O
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 KS = json.load(open(os.path.join(GOLDEN, "kstream_cases.json"))) + \
     json.load(open(os.path.join(GOLDEN, "kstream_cases_more.json"))) + \
-    json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json")))
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_routes.json"))) + \
+    json.load(open(os.path.join(GOLDEN, "kstream_cases_r6.json")))
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from golden_cases import FC as _FC0, FC6, canon_equal       # noqa: E402
