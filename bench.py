@@ -2,8 +2,10 @@
 """bench.py -- k-mers/s sorted + intersected (BASELINE.json metric) on MI355X.
 
 A "step" = one pass of the hot path over one batch of synthetic genomes that are already
-resident in HBM as ASCII bases: per genome pack -> both-strand keys -> MSD radix partition ->
-LDS sort, then the n-way intersection + diagnostic filter and the collection of the candidate
+resident in HBM as ASCII bases: per genome pack -> both-strand keys -> MSD radix partition into the
+fine buckets all genomes share (round 6: the order INSIDE a bucket is made where a reader needs it --
+KR_OPT_LAZY_ORDER; KR_LAZY_ORDER=0 ends every sort with the LDS sort as rounds 1-5 did), then the n-way
+intersection + diagnostic filter and the collection of the candidate
 records -- SURVEY 8(d): "from packed bases resident in HBM to filtered candidate records
 resident in HBM".  At N = 1 the default workload is BASELINE.json configs[1]: 4 synthetic 50 Mbp
 genomes (2 in / 2 out), k = 28 as 25/1/2.  At N > 1 every rank gets its own 4 genomes of one
@@ -614,8 +616,9 @@ def main():
             alg_bpk = None
             if not wide:
                 sb = stage_bytes
-                # (KR_OPT_LAZY_ORDER: the LDS sort reads and writes the anchor genome only -- one of per_gpu)
-                ls_share = (1.0 / per_gpu) if lazy["on"] and lazy["skipped"] else 1.0
+                # (KR_OPT_LAZY_ORDER: the LDS sort reads and writes the anchor genome only -- one of per_gpu --, and no genome
+                # at all where the intersection makes the anchor's slots itself: k_intersect3t<., UA>)
+                ls_share = 0.0 if lazy["anchor_in_bucket_order"] else ((1.0 / per_gpu) if lazy["on"] and lazy["skipped"] else 1.0)
                 alg_bpk = (sb["pack"] + sb["hist8"] + sb["scatter1"] + (2 * 0.1875 if nslices == 1 else sb["hist2"]) + sb["scatter2"]
                            + sb["localsort"] * ls_share + sb["intersect"])
             if step_roof is not None:
