@@ -500,16 +500,26 @@ def main():
     c3 = CONFIGS[3]
     if (args.config is None and not custom and world == c3["gpus"] and gen_8d and not args.no_configs3) or args.force_configs3:
         try:
-            for g in ids:
-                eng.free(g)
-            g3 = make_genomes(c3["gen"], rank, world, c3["per_gpu"], args.configs3_length or c3["length"])
-            eng.set_params(*c3["ldr"], omit_soft=False, max_bases=max(len(t) for _, _, t in g3))
-            ids3 = []
-            for g, ing, text in g3:
-                eng.upload(g, text)
-                ids3.append(g)
-            flags3 = [ing for _, ing, _ in g3]
-            del g3
+            # (what can fail on ONE rank -- memory for the larger genomes -- happens before the first exchange of this block,
+            # and every rank learns whether all got through: nobody enters the steps' collectives alone)
+            local_err, ids3, flags3 = None, [], []
+            try:
+                for g in ids:
+                    eng.free(g)
+                g3 = make_genomes(c3["gen"], rank, world, c3["per_gpu"], args.configs3_length or c3["length"])
+                eng.set_params(*c3["ldr"], omit_soft=False, max_bases=max(len(t) for _, _, t in g3))
+                for g, ing, text in g3:
+                    eng.upload(g, text)
+                    ids3.append(g)
+                flags3 = [ing for _, ing, _ in g3]
+                del g3
+            except Exception as e:  # noqa: BLE001
+                local_err = e
+            failed = 1.0 if local_err is not None else 0.0
+            if comm and world > 1:
+                failed = float(eng.comm_allreduce([failed], "max")[0])
+            if failed:
+                raise _native.KrispHipError(f"configs[3] block not run: {local_err or 'another rank could not set it up'}")
             st3, wu3 = 5, 2
             for _ in range(wu3):
                 D.sharded_step(eng, ids3, flags3, world, apply_filter=True, collect=True)
