@@ -195,7 +195,7 @@ def _prefix_key(left, right):
     return key
 
 
-def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter):
+def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter, rna_genomes=None):
     """The reference keeps k-mers with IUPAC letters (kstream.py:11-18); the device cannot pack
     them, so they arrive here as strings: specials[g] = [(left, diag, right), ...] of genome g.
     Every (left,right) group they touch is rebuilt exactly: its ACGT members are looked up on
@@ -215,23 +215,31 @@ def _special_groups(eng, ids, labels, specials, geo, ingroup, do_filter):
         cands["prefix"] = np.array(pure, dtype=np.uint64)
         eng.load_cands(cands)
         recs = eng.collect(ids)
-    return touched, _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter)
+    return touched, _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter, rna_genomes)
 
 
-def _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter):
+def _special_groups_from(recs, ids, labels, specials, geo, ingroup, do_filter, rna_genomes=None):
     """the groups IUPAC windows touch, from the device records of their ACGT members (`recs`: of one context, or
-    gathered from every rank of a multi-GPU run) and the IUPAC members themselves (specials[g] of genome ids[g])"""
+    gathered from every rank of a multi-GPU run) and the IUPAC members themselves (specials[g] of genome ids[g]).
+    rna_genomes (a run that mixes DNA and RNA genomes): the text of an RNA genome's members carries U -- the reference
+    compares text, so a group is a (left,right) pair every genome holds letter for letter"""
     L, D, R = geo
     members = {}            # (left,right) -> {(left,diag,right) -> {genome index -> count}}
+
+    def text_of(gi, l, d, r):
+        if rna_genomes is not None and rna_genomes[gi]:
+            return l.replace("T", "U"), d.replace("T", "U"), r.replace("T", "U")
+        return l, d, r
     if recs is not None:
         for rec in recs:
-            l, d, r = codec.key_columns(rec["key"], L, D, R)
             gi = ids.index(int(rec["genome"]))
+            l, d, r = text_of(gi, *codec.key_columns(rec["key"], L, D, R))
             members.setdefault((l, r), {}).setdefault((l, d, r), {})
             m = members[(l, r)][(l, d, r)]
             m[gi] = m.get(gi, 0) + int(rec["count"])
     for gi, sp in enumerate(specials):
         for (l, d, r) in sp:
+            l, d, r = text_of(gi, l, d, r)
             m = members.setdefault((l, r), {}).setdefault((l, d, r), {})
             m[gi] = m.get(gi, 0) + 1
     groups = []
@@ -280,7 +288,7 @@ def _wide_probe_members(eng, texts, gis, probes, probe_text, geo, pid):
     return members
 
 
-def _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do_filter):
+def _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do_filter, rna_genomes=None):
     """the groups IUPAC windows touch, from the ACGT members the device found (_wide_probe_members, of one context or
     merged over the ranks) and the IUPAC members themselves (specials[g] of genome g), under the reference's rules:
     present in every genome (intersectAmplicons.py:232-310), an ingroup-unique column (Amplicon.py:495-521)"""
@@ -288,6 +296,20 @@ def _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do
         for (l, d, r) in sp:
             m = members.setdefault((l, r), {}).setdefault((l, d, r), {})
             m[gi] = m.get(gi, 0) + 1
+    if rna_genomes is not None:
+        # (a run that mixes DNA and RNA genomes: every member as the text its genome's file holds -- U for an RNA genome --,
+        # grouped again on that text; pairs that hold T / U then lack the genomes of the other alphabet)
+        conv = {}
+        for P, seqs in members.items():
+            if P not in touched:
+                continue
+            for seq, m in seqs.items():
+                for gi, cnt in m.items():
+                    l, d, r = ((x.replace("T", "U") for x in seq) if rna_genomes[gi] else seq)
+                    mm = conv.setdefault((l, r), {}).setdefault((l, d, r), {})
+                    mm[gi] = mm.get(gi, 0) + cnt
+        members = conv
+        touched = set(conv)
     groups = []
     for P in sorted(members):
         if P not in touched:
@@ -310,13 +332,13 @@ def _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do
     return groups
 
 
-def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, geo, ingroup, do_filter):
+def _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, geo, ingroup, do_filter, rna_genomes=None):
     """Wide-path twin of _special_groups.  A touched (left,right) pair with an IUPAC letter in a
     flank can only hold IUPAC k-mers (the host has them all); a pair with plain flanks also
     holds ACGT windows, which the device locates (_wide_probe_members)."""
     n = len(texts)
     members = _wide_probe_members(eng, texts, list(range(n)), probes, probe_text, geo, pid=n)
-    return _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do_filter)
+    return _special_groups_wide_from(members, n, labels, specials, touched, ingroup, do_filter, rna_genomes)
 
 
 def _merge_groups(device_groups, touched, special_groups):
@@ -453,8 +475,6 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
         t3 = time.time()
         mixed = any(rna) and not all(rna)
         if mixed:
-            if any(specials):
-                raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
             eng.set_mixed_alphabets(True)
         finish = _to_rna if all(rna) else (lambda groups: groups)
         ids = list(range(len(files)))
@@ -470,7 +490,8 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
         records = eng.collect(by_label) if (ncand and not quirk_all_fail) else np.empty(0, dtype=_native.RECORD)
         touched, sgroups = set(), []
         if any(specials) and not quirk_all_fail:
-            touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels, do_filter)
+            touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels, do_filter,
+                                               rna_genomes=rna if mixed else None)
         t5 = time.time()
     # (device_s ends where the context is gone: its buffers freed, the reader threads joined)
     stats = {"read_s": read_s, "device_s": time.time() - t1,
@@ -481,6 +502,8 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
         return [], stats
     if mixed:
         groups = _mixed_finish(records, labels, (Le, De, Re), rna, ingroup_labels, do_filter)
+        if touched:
+            groups = _merge_groups(groups, touched, sgroups)
         stats["candidates"] = len(groups)
         return groups, stats
     if not touched and not any(rna):
@@ -735,8 +758,6 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
     specials = [[codec.split_window(w, Le, De, Re) for w in sp] for _, _, sp in loaded]
     rna = [bool(r) for _, r, _ in loaded]
     mixed = any(rna) and not all(rna)
-    if mixed and any(specials):
-        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
     finish = _to_rna if all(rna) else (lambda groups: groups)
     if len(files) == 1:
         # mergeFiles moves the lone k-mer file; its lines carry no label, so later stages
@@ -782,6 +803,10 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
                 groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
                 if do_filter and ingroup_labels:
                     groups = [g for g in groups if amplicon.ingroup_unique_columns(g, ingroup_labels)]
+                if touched:
+                    sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text,
+                                                   (Le, De, Re), ingroup_labels, do_filter, rna_genomes=rna)
+                    groups = _merge_groups(groups, touched | {(g[0].left, g[0].right) for g in sgroups}, sgroups)
                 ngroups = len(groups)
                 finish = lambda g: g        # noqa: E731
             elif touched:
@@ -820,13 +845,15 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
         touched, sgroups = set(), []
         if any(specials) and not quirk_all_fail:
             touched, sgroups = _special_groups(eng, ids, labels, specials, (Le, De, Re), ingroup_labels,
-                                               do_filter)
+                                               do_filter, rna_genomes=rna if mixed else None)
     stats.update(device_s=time.time() - t1, kmers=int(sum(counts)) + sum(len(sp) for sp in specials),
                  candidates=int(ncand))
     if quirk_all_fail:
         return [], stats
     if mixed:
         groups = _mixed_finish(records, labels, (Le, De, Re), rna, ingroup_labels, do_filter)
+        if touched:
+            groups = _merge_groups(groups, touched, sgroups)
         stats["candidates"] = len(groups)
         return groups, stats
     if not touched and not any(rna):
@@ -894,9 +921,20 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
                                     1.0 if any(r for _, r, _ in loaded) else 0.0,
                                     float(max(len(b) for b, _, _ in loaded)),
                                     1.0 if any(not r for _, r, _ in loaded) else 0.0], "max")
-        if kinds[1] and kinds[3]:
-            raise MixedAlphabet("some genomes are RNA (U) and some DNA (T)")
-        all_rna = bool(kinds[1])
+        mixed = bool(kinds[1] and kinds[3])
+        all_rna = bool(kinds[1]) and not mixed
+        rna_all = None
+        if mixed:
+            # DNA and RNA genomes in one run (round 6; find_regions has the rules): every rank learns every genome's alphabet,
+            # every context filters in mode 2, the candidates whose (left,right) pair holds T / U go, rank 0 decides the rest on text
+            if kinds[0]:
+                raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
+            import json
+            rna_all = [False] * len(order)
+            for blob in eng.comm_allgather(json.dumps({int(g): bool(r) for g, (_, r, _) in zip(mine, loaded)}).encode()):
+                for g, r in json.loads(blob.decode()).items():
+                    rna_all[int(g)] = bool(r)
+            eng.set_mixed_alphabets(True)
         # windows with IUPAC letters (kept by the reference, kstream.py:11-18; the device alphabet cannot carry them):
         # every rank learns all of them -- they are rare --, the groups they touch are rebuilt on rank 0 from the
         # ranks' device look-ups of the ACGT members (below), as find_regions does on one GPU
@@ -971,7 +1009,13 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
             for g in sorted(set(hits["genome"].tolist())):
                 if texts[g] is None:
                     texts[g] = fasta.ingest(order[g], k, omit_soft)[0]
-            wg = _groups_from_hits(hits, texts, labels, Le, De, Re)
+            wg = _groups_from_hits(hits, texts, labels, Le, De, Re, rna_genomes=rna_all)
+            if mixed:
+                wg = [g for g in wg if not (set(g[0].left + g[0].right) & set("TU"))]
+                if do_filter and ingroup_labels:
+                    wg = [g for g in wg if amplicon.ingroup_unique_columns(g, ingroup_labels)]
+                stats["candidates"] = len(wg)
+                return wg, stats
             if wide_sp is not None:
                 touched_w, members_w = wide_sp
                 sg = _special_groups_wide_from(members_w, len(order), labels, specials_all, touched_w, ingroup_labels, do_filter)
@@ -1048,6 +1092,8 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
             batched[0] = len(mine)
         ncand = eng.cands_reduce(apply_filter=filt)
         eng.cands_bcast()
+        if mixed:
+            together(lambda: _mixed_prefix_filter(eng, Le, Re))       # (the same list on every rank: the same cut)
         if any_batched:
             myrec = together(lambda: np.empty(0, dtype=_native.RECORD) if quirk_all_fail else collect_shard())
             nrec = len(myrec)
@@ -1084,6 +1130,10 @@ def _distributed_rank(rank, world, device, connect, ingroup_files, outgroup_file
         return None, stats
     if quirk_all_fail:
         return [], stats
+    if mixed:
+        groups = _mixed_finish(allrec, labels, (Le, De, Re), rna_all, ingroup_labels, do_filter)
+        stats["candidates"] = len(groups)
+        return groups, stats
     finish = _to_rna if all_rna else (lambda groups: groups)
     if not touched and not all_rna:
         return amplicon.RecordGroups(allrec, labels, Le, De, Re), stats
@@ -1370,7 +1420,8 @@ def _merge_files_wide(contents, labels, L, D, R, device):
             # the plain members the device finds for their (left,right) pairs, as find_regions does (round 6: refused before)
             sp = [ln for ln in lines if ln.translate(None, plain)]
             lines = [ln for ln in lines if not ln.translate(None, plain)]
-            specials.append([tuple(x.decode() for x in ln.split(b",")) for ln in sp])
+            # (inside, an RNA file's lines are handled with T like its plain lines; they get their U back at the end)
+            specials.append([tuple(x.decode().replace("U", "T") if rna else x.decode() for x in ln.split(b",")) for ln in sp])
         else:
             specials.append([])
         rec = [ln.replace(b",", b"") for ln in lines]
@@ -1380,8 +1431,6 @@ def _merge_files_wide(contents, labels, L, D, R, device):
         texts.append(np.frombuffer(t.replace(b"U", b"T") if rna else t, dtype=np.uint8))
     ids = list(range(len(texts)))
     mixed = any(rnas) and not all(rnas)
-    if any(specials) and any(rnas):
-        raise MixedAlphabet("k-mer files of RNA genomes that hold IUPAC letters, amplicons longer than one key")
     touched = {(l, r) for sp in specials for (l, d, r) in sp}
     probes = sorted(p for p in touched if _pure(p[0]) and _pure(p[1]))
     probe_text = np.frombuffer("\n".join(l + "A" * D + r for l, r in probes).encode(), dtype=np.uint8)
@@ -1398,7 +1447,10 @@ def _merge_files_wide(contents, labels, L, D, R, device):
         if mixed:
             groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
         if touched:
-            sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, (L, D, R), frozenset(), False)
+            sgroups = _special_groups_wide(eng, texts, labels, specials, touched, probes, probe_text, (L, D, R), frozenset(), False,
+                                           rna_genomes=rnas if any(rnas) else None)
+            if any(rnas):       # (the device's groups of the touched pairs carry U where their files do)
+                touched = touched | {(l.replace("T", "U"), r.replace("T", "U")) for l, r in touched}
             groups = _merge_groups(groups, touched, sgroups)
     return groups
 
@@ -1508,7 +1560,8 @@ def build_parser():
                                        "    memory holds at all); with amplicons longer than 32 bases, 2^32 bases;\n"
                                        "  * amplicons longer than 32 bases (or more than 16 diagnostic bases): conserved flanks of 1 .. 256\n"
                                        "    bases each, amplicons of at most 1024;\n"
-                                       "  * DNA and RNA genomes in one run together with IUPAC ambiguity letters, or over several ranks.\n"
+                                       "  * DNA and RNA genomes in one run together with IUPAC ambiguity letters when the genome set goes through the\n"
+                                       "    GPU in batches or over several ranks.\n"
                                        "A genome set that does not fit the GPU's memory sorted at once goes through it in batches\n"
                                        "(same result; KRISP_STREAM_BATCH=n forces batches of n genomes).")
     p.add_argument("files", nargs="+", type=str, metavar="PATH", help="Fasta file to read. .gz, .bz2")

@@ -725,6 +725,30 @@ def fasta_cases_r6():
         c = run_fasta_case(name, files, ing, outg, L, D, R, hash_big=True, run_main=False)
         c["files"] = {fn: v.decode() for fn, v in files.items()}
         cases.append(c)
+    # ---- DNA + RNA genomes AND IUPAC ambiguity letters in one run (stages only: the renderer dies on U / lone letters)
+    for name, kinds_in, kinds_out, (L, D, R), glen, rate, tf in [
+            ("mixed_iupac_6_1_3", [False, True], [True, False], (6, 1, 3), 900, 0.01, 0.2),
+            ("mixed_iupac_in_dna_out_rna_5_2_4", [False, False], [True], (5, 2, 4), 800, 0.01, 0.25),
+            ("mixed_iupac_wide_18_6_18", [False, True], [True], (18, 6, 18), 1500, 0.003, 0.03),
+    ]:
+        anc, plants = family(len(kinds_in) + len(kinds_out), glen, rate, L, D, R, t_frac=tf)
+        files, ing, outg = {}, [], []
+        for i, rna in enumerate(kinds_in + kinds_out):
+            is_in = i < len(kinds_in)
+            text = genome(anc, plants, rate, is_in, False).decode()
+            m = list(text)
+            body = [j for j, ch in enumerate(m) if ch in "ACGT"]
+            for j in rng.sample(body, 5):
+                m[j] = rng.choice("RYKMSW")
+            text = "".join(m)
+            if rna:
+                text = text.replace("T", "U").replace("t", "u")
+            fn = f"in{i}.fa" if is_in else f"out{i - len(kinds_in)}.fasta"
+            files[fn] = text.encode()
+            (ing if is_in else outg).append(fn)
+        c = run_fasta_case(name, files, ing, outg, L, D, R, hash_big=True, run_main=False)
+        c["files"] = {fn: v.decode() for fn, v in files.items()}
+        cases.append(c)
     return cases
 
 
