@@ -112,6 +112,12 @@ int kr_set_allow(kr_ctx*, unsigned base_mask);
  * prefix is the krisp_fasta layout's -- refuse it. */
 int kr_set_field_order(kr_ctx*, const int widths[3], const int order[3]);
 
+/* ... and the column orders kr_set_field_order cannot hold (round 6): the key = the n <= 8 listed pieces of the window one after the
+ * other, piece i = the widths[i] >= 1 bases at window offset offsets[i]; the pieces partition the window.  For split lists
+ * with two or more sizes counted from the end (kstream.py:805-832: the line's columns then leave window order) and column
+ * lists that cut the window into more than three blocks.  Same preconditions and the same sort-only context. */
+int kr_set_field_pieces(kr_ctx*, int n, const int* offsets, const int* widths);
+
 /* H2D copy of one genome's text + all device allocations it needs. */
 int kr_genome_upload(kr_ctx*, int genome_id, const uint8_t* bases, size_t n_bases);
 /* pack -> both-strand keys -> MSD radix partition -> LDS sort.  Asynchronous.  Under KR_OPT_LAZY_ORDER (the default) the

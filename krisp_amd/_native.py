@@ -59,6 +59,7 @@ SYMBOLS = [
     ("kr_genome_keys_in_order", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_set_allow", _c.c_int, [_P, _c.c_uint]),
     ("kr_set_field_order", _c.c_int, [_P, _P, _P]),
+    ("kr_set_field_pieces", _c.c_int, [_P, _c.c_int, _P, _P]),
     ("kr_genome_free", _c.c_int, [_P, _c.c_int]),
     ("kr_intersect", _c.c_int64, [_P, _P, _c.c_int, _P, _c.c_int]),
     ("kr_cands_count", _c.c_int64, [_P]),
@@ -447,6 +448,12 @@ class Engine:
         w = np.asarray(list(widths) + [0] * (3 - len(widths)), dtype=np.int32)
         o = np.asarray(order, dtype=np.int32)
         self._check(self.lib.kr_set_field_order(self.ctx, _ptr(w), _ptr(o)), "kr_set_field_order")
+
+    def set_field_pieces(self, pieces):
+        """the key = the window's pieces [(offset, width)] one after the other (kr_set_field_pieces); after set_params(k, 0, 0)"""
+        o = np.asarray([p[0] for p in pieces], dtype=np.int32)
+        w = np.asarray([p[1] for p in pieces], dtype=np.int32)
+        self._check(self.lib.kr_set_field_pieces(self.ctx, len(pieces), _ptr(o), _ptr(w)), "kr_set_field_pieces")
 
     def keys_in_order(self, gid, n_bases):
         """keys of an uploaded genome in stream order (no sort)"""

@@ -49,17 +49,39 @@ def keys_to_lines_bytes(keys, L, D, R, rna=False):
     return out.tobytes()
 
 
+class Fields(list):
+    """the widths of a line's columns, in line order (empty ones included) + `.offsets`: where each column starts in the
+    WINDOW.  kstream's split takes sizes off the front and off the end of the k-mer in turn (kstream.py:805-832) and writes
+    the end parts in the order they were cut: with two or more of them the line's columns are not in window order."""
+
+    def __init__(self, widths, offsets=None):
+        super().__init__(widths)
+        if offsets is None:
+            offsets, at = [], 0
+            for w in widths:
+                offsets.append(at)
+                at += w
+        self.offsets = list(offsets)
+
+    def in_window_order(self):
+        live = [(o, w) for o, w in zip(self.offsets, self) if w > 0]
+        return all(a[0] + a[1] == b[0] for a, b in zip(live, live[1:])) and (not live or live[0][0] == 0)
+
+
+def field_offsets(fields):
+    return fields.offsets if isinstance(fields, Fields) else Fields(fields).offsets
+
+
 def keys_to_fields_bytes(keys, fields, rna=False):
-    """keys whose bases are the window in line order (engine geometry (k, 0, 0)) -> bytes of the
-    sorted output: the window cut into `fields` (widths, empty ones included) joined by ','."""
+    """keys whose bases are the WINDOW (engine geometry (k, 0, 0)) -> bytes of the output: the window's pieces `fields`
+    (widths in line order, empty ones included; Fields.offsets: where each lies in the window) joined by ','."""
     k = sum(fields)
     m = keys_to_matrix(keys, k, 0, 0, rna)
     out = np.empty((len(m), k + len(fields)), dtype=np.uint8)
-    src = dst = 0
-    for w in fields:
+    dst = 0
+    for w, src in zip(fields, field_offsets(fields)):
         out[:, dst:dst + w] = m[:, src:src + w]
         out[:, dst + w] = ord(",")
-        src += w
         dst += w + 1
     out[:, k + len(fields) - 1] = ord("\n")
     return out.tobytes()
@@ -96,21 +118,35 @@ def merge_fields(fields, order):
     """the window's fields (widths, line order) in key order `order`, with neighbouring fields that stay neighbours and in
     order fused into blocks: (block widths in line order, their key order) -- what kr_set_field_order takes when the blocks
     are at most three --, or None.  Empty fields join the block in front of them."""
+    off = field_offsets(fields)
     live = [f for f in order if fields[f] > 0]
-    runs = []                                   # maximal runs f, f + 1, ... (over the non-empty fields) inside `live`
-    nonempty = [f for f in range(len(fields)) if fields[f] > 0]
-    nxt = {a: b for a, b in zip(nonempty, nonempty[1:])}
+    runs = []                                   # maximal runs of fields that follow each other in the WINDOW, inside `live`
     for f in live:
-        if runs and nxt.get(runs[-1][-1]) == f:
+        if runs and off[runs[-1][-1]] + fields[runs[-1][-1]] == off[f]:
             runs[-1].append(f)
         else:
             runs.append([f])
     if len(runs) > 3:
         return None
-    by_line = sorted(range(len(runs)), key=lambda i: runs[i][0])          # blocks in line order
-    widths = [sum(fields[f] for f in runs[i]) for i in by_line]
-    rank = {i: j for j, i in enumerate(by_line)}
+    by_window = sorted(range(len(runs)), key=lambda i: off[runs[i][0]])   # blocks in window order (kr_set_field_order's widths)
+    widths = [sum(fields[f] for f in runs[i]) for i in by_window]
+    rank = {i: j for j, i in enumerate(by_window)}
     return widths, [rank[i] for i in range(len(runs))]
+
+
+def key_pieces(fields, order):
+    """the window's pieces in KEY order for kr_set_field_pieces: [(offset, width)] of the non-empty fields in `order`,
+    neighbours in the window fused"""
+    off = field_offsets(fields)
+    out = []
+    for f in order:
+        if fields[f] <= 0:
+            continue
+        if out and out[-1][0] + out[-1][1] == off[f]:
+            out[-1] = (out[-1][0], out[-1][1] + fields[f])
+        else:
+            out.append((off[f], fields[f]))
+    return out
 
 
 def keys_to_ordered_fields_bytes(keys, fields, order, rna=False):
@@ -134,10 +170,7 @@ def keys_to_ordered_fields_bytes(keys, fields, order, rna=False):
 
 def order_string(s, fields, order):
     """the window string s with its fields (widths `fields`, line order) rearranged into `order`: what the sort compares"""
-    cuts, at = [], 0
-    for w in fields:
-        cuts.append(s[at:at + w])
-        at += w
+    cuts = [s[o:o + w] for o, w in zip(field_offsets(fields), fields)]
     return "".join(cuts[f] for f in order)
 
 
@@ -183,10 +216,7 @@ def merged_ordered_blocks(keys, specials, fields, order, rna=False, chunk=1 << 2
             pos = end
         while ci < len(cuts) and cuts[ci][0] <= pos:
             s = cuts[ci][1]
-            parts, at = [], 0
-            for w in fields:
-                parts.append(s[at:at + w])
-                at += w
+            parts = [s[o:o + w] for o, w in zip(field_offsets(fields), fields)]
             line = ",".join(parts) + "\n"
             if rna:
                 line = line.replace("T", "U").replace("t", "u")

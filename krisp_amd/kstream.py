@@ -124,8 +124,9 @@ class kstream:
         Not on the device, with the reason in `plan_reason`:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
             formed before the filters);
-          * two or more split points counted from the end (the line's columns then leave window order), or a custom
-            column order that cuts the window into more than three blocks;
+          * a column order that cuts the window into more than eight pieces (any split list, any column list below that
+            has a key layout: three blocks by shifts, kr_set_field_order; more, or pieces out of window order -- two
+            split sizes counted from the end --, piece by piece, kr_set_field_pieces);
           * k > 32 outside the krisp_fasta combination or without --sort, flanks > 256, k > 1024;
           * a custom column order on an input large enough to need key-space slices (> 2^28 bases: decided at run time)."""
         self.plan_reason = None
@@ -173,16 +174,20 @@ class kstream:
             # is left, a negative one off its END --, the line is front parts + what is left + end parts, the end parts in
             # the order they were cut.  Any number of sizes (round 6: two at most before) whose parts come out in WINDOW
             # order: at most one of them negative (a second end part would stand behind the first in the line, in front
-            # of it in the window).  -0 is 0: an empty front part (kstream.py:824-830).
-            head, tail, left = [], [], k
+            # of it in the window: codec.Fields keeps every column's place in the window).  -0 is 0: an empty front part
+            # (kstream.py:824-830).
+            head, tail, lo, hi = [], [], 0, k
             for z in self.split:
-                if (z >= 0 and z > left) or (z < 0 and -z > left):
+                if (z >= 0 and z > hi - lo) or (z < 0 and -z > hi - lo):
                     return self._no_plan("split point outside the k-mer")
-                (head if z >= 0 else tail).append(abs(z))
-                left -= abs(z)
-            if len(tail) > 1:
-                return self._no_plan("two or more split points counted from the end: the line's columns leave window order")
-            fields = head + [left] + tail
+                if z >= 0:
+                    head.append((lo, z))
+                    lo += z
+                else:
+                    tail.append((hi + z, -z))
+                    hi += z
+            pieces = head + [(lo, hi - lo)] + tail                  # (offset in the window, width) of the line's columns
+            fields = codec.Fields([w for _, w in pieces], [o for o, _ in pieces])
         common = dict(k=k, fields=fields, strands=strands, allow=allow_bases, keepcase=keepcase, expand=self.expandiupac)
         if self.sort is False:
             if k > 32:
@@ -199,7 +204,8 @@ class kstream:
                 order.append(c)
         live = [c for c in order if fields[c] > 0]             # empty fields do not order anything
         natural = [c for c in range(len(fields)) if fields[c] > 0]
-        krisp_order = len(fields) == 3 and live == [c for c in (0, 2, 1) if fields[c] > 0]
+        in_window_order = codec.Fields(fields, codec.field_offsets(fields)).in_window_order()
+        krisp_order = in_window_order and len(fields) == 3 and live == [c for c in (0, 2, 1) if fields[c] > 0]
         if k > 32:
             # amplicons longer than one key: the wide path sorts the krisp_fasta combination (krisp_fasta.py:21-43)
             from . import _native
@@ -213,7 +219,7 @@ class kstream:
         if krisp_order and fields[1] <= 16:
             layout, geometry = "lrd", (fields[0], fields[1], fields[2])
             order = [0, 2, 1]
-        elif live == natural:
+        elif live == natural and in_window_order:
             layout, geometry = "ldr", (k, 0, 0)
             order = list(range(len(fields)))
         else:
@@ -221,7 +227,9 @@ class kstream:
             order = live + [c for c in range(len(fields)) if c not in live]
             merged = codec.merge_fields(fields, order)
             if merged is None or not codec.field_layout_ok(*merged):
-                return self._no_plan("this column order cuts the window into more than three blocks: no key layout holds it")
+                # (more than three blocks: the key as a list of pieces -- kr_set_field_pieces, round 6)
+                if len(codec.key_pieces(fields, order)) > 8:
+                    return self._no_plan("this column order cuts the window into more than eight pieces: no key layout holds it")
         # (--expand-iupac: windows holding N are dropped before the expansion -- the disallow / allow test above --, so an
         # expansion is the handful of combinations of a window's other ambiguity letters)
         return dict(common, layout=layout, order=order, geometry=geometry, sorted=True)
@@ -345,8 +353,12 @@ class kstream:
                     # first bases of `left`, which a custom layout moves away from the top of the key)
                     self.plan_reason = "a custom column order on an input that needs key-space slices"
                     return None
-                mf, mo = codec.merge_fields(fields, order)      # (neighbouring columns that stay neighbours are one block of the key)
-                eng.set_field_order(mf + [0] * (3 - len(mf)), mo + list(range(len(mf), 3)))
+                merged = codec.merge_fields(fields, order)      # (neighbouring columns that stay neighbours are one block of the key)
+                if merged is not None and codec.field_layout_ok(*merged):
+                    mf, mo = merged
+                    eng.set_field_order(mf + [0] * (3 - len(mf)), mo + list(range(len(mf), 3)))
+                else:
+                    eng.set_field_pieces(codec.key_pieces(fields, order))
             if plan["strands"]:
                 eng.set_strands(plan["strands"])
             if allow is not None:
