@@ -127,8 +127,7 @@ class kstream:
           * a column order that cuts the window into more than eight pieces (any split list, any column list below that
             has a key layout: three blocks by shifts, kr_set_field_order; more, or pieces out of window order -- two
             split sizes counted from the end --, piece by piece, kr_set_field_pieces);
-          * k > 32 outside the krisp_fasta combination or without --sort, flanks > 256, k > 1024;
-          * a custom column order on an input large enough to need key-space slices (> 2^28 bases: decided at run time)."""
+          * k > 32 outside the krisp_fasta combination or without --sort, flanks > 256, k > 1024."""
         self.plan_reason = None
         if self.kmers is None or len(self.kmers) < 1:
             return self._no_plan("no k given: the sequences pass through as they are")
@@ -348,11 +347,6 @@ class kstream:
             # (lower case kept: the device takes the windows without any, as under omitsoft; the others are `special`)
             eng.set_params(L, D, R, omit_soft=self.omitsoft or plan["keepcase"], max_bases=len(bases))
             if plan["layout"] == "custom":
-                if eng.debug_info()["nslices"] > 1:
-                    # (a genome of more than 2^28 bases -- or KR_SLICE_BASES in the environment --: the slice digits are the
-                    # first bases of `left`, which a custom layout moves away from the top of the key)
-                    self.plan_reason = "a custom column order on an input that needs key-space slices"
-                    return None
                 merged = codec.merge_fields(fields, order)      # (neighbouring columns that stay neighbours are one block of the key)
                 if merged is not None and codec.field_layout_ok(*merged):
                     mf, mo = merged
