@@ -123,7 +123,8 @@ class kstream:
         through the reference's chain on the host by itself and joins the sorted stream.
         Not on the device, with the reason in `plan_reason`:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
-            formed before the filters);
+            formed before the filters), in stream order (sorted: two forward passes, over the sequences and their
+            reverse complements);
           * a column order that cuts the window into more than eight pieces (any split list, any column list below that
             has a key layout: three blocks by shifts, kr_set_field_order; more, or pieces out of window order -- two
             split sizes counted from the end --, piece by piece, kr_set_field_pieces);
@@ -163,8 +164,15 @@ class kstream:
         if self.disallow is not None:
             base_ok -= self.disallow
         allow_bases = None if base_ok == set("ACGT") else "".join(sorted(base_ok))
+        split_strands = False
         if strands == 0 and {COMP_MAP[b] for b in base_ok} != base_ok:
-            return self._no_plan("the bases --allow / --disallow leave are not closed under complement while both strands are emitted")
+            # a window and its reverse complement are filtered each by itself (the complements are formed BEFORE the filters,
+            # kstream.py:696-766): one strand may stay where the other goes.  Sorted streams (round 6): two forward-only
+            # passes -- over the sequences and over their reverse complements -- merged; in stream order a window's two
+            # k-mers would have to be told apart on the device: host chain
+            if self.sort is not True:
+                return self._no_plan("the bases --allow / --disallow leave are not closed under complement while both strands are emitted, in stream order")
+            split_strands = True
         # fields of the output line (kstream.py:805-832)
         if self.split is None:
             fields = [k]
@@ -187,7 +195,8 @@ class kstream:
                     hi += z
             pieces = head + [(lo, hi - lo)] + tail                  # (offset in the window, width) of the line's columns
             fields = codec.Fields([w for _, w in pieces], [o for o, _ in pieces])
-        common = dict(k=k, fields=fields, strands=strands, allow=allow_bases, keepcase=keepcase, expand=self.expandiupac)
+        common = dict(k=k, fields=fields, strands=strands, allow=allow_bases, keepcase=keepcase, expand=self.expandiupac,
+                      split_strands=split_strands)
         if self.sort is False:
             if k > 32:
                 return self._no_plan("k > 32 without --sort")
@@ -355,9 +364,20 @@ class kstream:
                     eng.set_field_pieces(codec.key_pieces(fields, order))
             if plan["strands"]:
                 eng.set_strands(plan["strands"])
+            elif plan.get("split_strands"):
+                eng.set_strands(_native.STRANDS_FORWARD)
             if allow is not None:
                 eng.set_allow(allow)
-            if plan["sorted"]:
+            if plan.get("split_strands"):
+                # (the reverse complement of every record: a k-mer of it that the base mask lets through is the reverse
+                # complement of a window whose own k-mer may have been dropped, and the other way round)
+                comp = np.arange(256, dtype=np.uint8)
+                for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+                    comp[a] = b
+                eng.add(0, bases)
+                eng.add(1, np.ascontiguousarray(comp[bases[::-1]]))
+                keys = np.sort(np.concatenate([eng.keys(0), eng.keys(1)]), kind="stable")
+            elif plan["sorted"]:
                 eng.add(0, bases)
                 keys = eng.keys(0).copy()
             else:
