@@ -407,6 +407,18 @@ def kstream_cases_r6():
     add("msplit_expand", dict(kmers=8, complements=True, disallow="Nn", mapsoft=True, sort=True, expandiupac=True, split=[2, 2, -2],
                               sortcols=[3, 0]), file_text=texts[1], fname="e.fa")
     add("msplit_allow", dict(kmers=8, allow="ACGT", sort=True, split=[3, 2, -1], sortcols=[2]), file_text=texts[1], fname="a.fa")
+    # --allow / --disallow sets that leave bases the two strands do not share, sorted: a window and its reverse complement
+    # are filtered each by itself (kstream.py:696-766 -- the complements are formed first)
+    low_t = fasta("ACG" * 10 + "T" + "acg" + "N", 4, 30, 80)
+    for j, (kw, text) in enumerate([
+            (dict(kmers=5, complements=True, allow="ACG", sort=True, mapsoft=True), low_t),
+            (dict(kmers=4, complements=True, disallow="TtNn", sort=True, mapsoft=True, split=[1, -1], sortcols=[2, 0]), low_t),
+            (dict(kmers=6, complements=True, allow="ACGacg", sort=True, split=[2, 2]), low_t),
+            (dict(kmers=5, complements=True, disallow="A", sort=True, omitsoft=True, split=[2]), texts[0]),
+            (dict(kmers=4, complements=True, allow="CGT", disallow="Nn", sort=True, mapsoft=True, split=[1, 1, -1], sortcols=[3]), texts[1]),
+            (dict(kmers=[4, 5], complements=True, allow="AG", sort=True, mapsoft=True), low_t),
+    ]):
+        add(f"strandsplit{j}", kw, file_text=text, fname="s.fa", use_write=bool(j % 2))
     return cases
 
 
