@@ -408,6 +408,8 @@ def _device_ingest_flow(files, ingroup_files, L, R, k, geo, omit_soft, device, v
                 return [], stats
             if stats.get("mixed_rna"):
                 groups = _mixed_finish(records, labels, (Le, De, Re), stats["mixed_rna"], ingroup_labels, do_filter)
+                if touched:
+                    groups = _merge_groups(groups, touched, sgroups)
                 stats["candidates"] = len(groups)
                 return groups, stats
             if not touched and not all_rna:
@@ -681,8 +683,6 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
     if mixed and running[0]:
         running[0] = _mixed_prefix_filter(eng, Le, Re)
     final = eng.cands().copy() if running[0] else np.empty(0, dtype=_native.CAND)
-    if mixed and any(sp for sp in specials if sp):
-        raise MixedAlphabet("some genomes are RNA (U) and some DNA (T), and windows hold IUPAC letters")
     stats["mixed_rna"] = [bool(r) for r in rna] if mixed else None
     touched = {(l, r) for sp in specials for (l, d, r) in sp} if not quirk_all_fail else set()
     pure = sorted({_prefix_key(l, r) for (l, r) in touched if _pure(l) and _pure(r)})
@@ -712,7 +712,7 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
     if touched:
         recs = np.concatenate(srecs) if srecs else None
         sgroups = _special_groups_from(recs, list(range(n)), labels, specials, geo, frozenset(l for l, f in zip(labels, flags) if f),
-                                       do_filter)
+                                       do_filter, rna_genomes=[bool(r) for r in rna] if mixed else None)
     stats.update(read_s=read_s[0] or 0.0, kmers=int(sum(counts)) + sum(len(sp) for sp in specials), candidates=int(len(final)))
     return records, touched, sgroups, all(rna), stats
 
@@ -1560,8 +1560,7 @@ def build_parser():
                                        "    memory holds at all); with amplicons longer than 32 bases, 2^32 bases;\n"
                                        "  * amplicons longer than 32 bases (or more than 16 diagnostic bases): conserved flanks of 1 .. 256\n"
                                        "    bases each, amplicons of at most 1024;\n"
-                                       "  * DNA and RNA genomes in one run together with IUPAC ambiguity letters when the genome set goes through the\n"
-                                       "    GPU in batches or over several ranks.\n"
+                                       "  * DNA and RNA genomes in one run together with IUPAC ambiguity letters over several ranks.\n"
                                        "A genome set that does not fit the GPU's memory sorted at once goes through it in batches\n"
                                        "(same result; KRISP_STREAM_BATCH=n forces batches of n genomes).")
     p.add_argument("files", nargs="+", type=str, metavar="PATH", help="Fasta file to read. .gz, .bz2")
