@@ -701,6 +701,72 @@ def test_random_genomes_with_iupac_letters_match_the_text_oracle(seed, tmp_path)
     assert sorted(amplicon.merged_lines(groups)) == sorted(expect)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_MIXED_SEEDS", "24"))))
+def test_random_mixed_dna_and_rna_runs_match_the_text_oracle(seed, tmp_path, monkeypatch):
+    """round 6: DNA and RNA genomes in one run.  The reference compares text, so a T and a U never
+    match (kstream.py:481-508, 585-615 map each file back to its own alphabet): only T/U-free flank pairs survive the
+    merge, and a T against a U in a diagnostic column separates the two.  Random families poor in T (or flanks would not
+    survive), one to three of the genomes RNA on either side, with repeats, N runs, lower case, several records, every
+    third seed with IUPAC letters; short amplicons (the packed path, filter mode 2 on the device) and amplicons longer
+    than one key (the wide path), in core, in batches (KRISP_STREAM_BATCH) and over two ranks -- against the text oracle's
+    stages (its renderer stops on a T/U column as the reference's does: the stages are what is pinned)."""
+    import random
+    from krisp_amd import amplicon
+    from krisp_amd import krisp_fasta as KF
+    from oracle import krisp_oracle as O
+    rng = random.Random(31000 + seed)
+    L, D, R = rng.choice([(4, 1, 2), (5, 2, 4), (8, 1, 7), (3, 3, 3), (12, 1, 6), (6, 4, 6)] if seed % 2 == 0 else
+                         [(12, 14, 10), (20, 1, 16), (6, 30, 6), (33, 2, 8), (9, 20, 40)])
+    k = L + D + R
+    n_in, n_out = rng.randint(1, 3), rng.randint(1, 2)
+    n = rng.randint(400, 2500)
+    anc = rng.choices("ACGT", weights=[32, 32, 32, 4], k=n)
+    if rng.random() < 0.5:
+        a, ln = rng.randrange(n // 2), rng.randint(30, 120)
+        anc[n // 2:n // 2 + ln] = anc[a:a + ln]
+    kinds = [rng.random() < 0.5 for _ in range(n_in + n_out)]
+    if all(kinds) or not any(kinds):
+        kinds[rng.randrange(len(kinds))] ^= True                     # (a mixed run, always)
+    ing, outg = [], []
+    for gi in range(n_in + n_out):
+        s = list(anc)
+        for _ in range(rng.randint(0, max(1, n // 50))):
+            s[rng.randrange(n)] = rng.choice("ACGT")
+        for _ in range(rng.randint(0, 2)):
+            a = rng.randrange(n)
+            s[a:a + rng.randint(1, 4)] = "N" * rng.randint(1, 4)
+        if seed % 3 == 2:
+            for _ in range(rng.randint(1, 4)):
+                s[rng.randrange(len(s))] = rng.choice("RYKMSWry")
+        if rng.random() < 0.5:
+            a = rng.randrange(len(s))
+            w = rng.randint(3, 40)
+            s[a:a + w] = [c.lower() for c in s[a:a + w]]
+        cut = rng.randrange(len(s))
+        text = ">r1\n" + "".join(s[:cut]) + "\n>r2 x\n" + "".join(s[cut:]) + "\n"
+        if kinds[gi]:
+            text = text.replace("T", "U").replace("t", "u")
+        p = tmp_path / f"{'in' if gi < n_in else 'out'}{gi}.fa"
+        p.write_text(text)
+        (ing if gi < n_in else outg).append(str(p))
+    omit = rng.random() < 0.3
+    sf = [(f"{O.basename(f)}.{k}mers", O.extract_sorted_kmers(f, L, R, k, omit)) for f in ing + outg]
+    merged = O.merge_tree(sf)
+    expect = sorted(O.filter_lines(merged, [O.simplename(f) for f in ing]))
+    print(f"mixed seed {seed}: {L}/{D}/{R}, {len(merged)} merged lines, {len(expect)} after the filter")
+    monkeypatch.delenv("KRISP_STREAM_BATCH", raising=False)
+    groups, stats = KF.find_regions(ing, outg, L, R, k, omit_soft=omit)
+    assert sorted(amplicon.merged_lines(groups)) == expect
+    if seed % 4 == 1:
+        monkeypatch.setenv("KRISP_STREAM_BATCH", "2")
+        groups, stats = KF.find_regions(ing, outg, L, R, k, omit_soft=omit)
+        assert sorted(amplicon.merged_lines(groups)) == expect
+        monkeypatch.delenv("KRISP_STREAM_BATCH")
+    if seed % 4 == 3 and seed % 3 != 2:          # (IUPAC windows of mixed sets over several ranks: the documented limit)
+        groups, _ = KF.find_regions_multi_device(ing, outg, L, R, k, [0, 0], omit_soft=omit)
+        assert sorted(amplicon.merged_lines(groups)) == expect
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_iupac_letters_and_rna_over_several_ranks(seed, tmp_path):
     """The multi-GPU flow keeps what the one-GPU flow keeps: windows with IUPAC ambiguity letters (every rank

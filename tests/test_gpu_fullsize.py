@@ -259,7 +259,8 @@ def test_c3_eight_half_gbp_genomes_long_amplicons(mu, records, snp_every, min_gr
     one flank pair per group, a diagnostic column separates the groups).  Two inputs, named by their ids: SURVEY
     8(d)'s own generator (mu = 0.01, 16 records, a planted SNP per 10 kb: what `bench.py --config 2` times) and
     round 2's family of close relatives (mu = 0.001: ten times as many flanks survive the spectrum phase, > 10^5
-    groups to cut and render)"""
+    groups to cut and render).  Round 6: one left-flank slice of the result (1/1024 of the key space) is compared with
+    the oracle line for line."""
     import time
     from krisp_amd import _native, amplicon, synth
     from krisp_amd import krisp_fasta as KF
@@ -312,8 +313,22 @@ def test_c3_eight_half_gbp_genomes_long_amplicons(mu, records, snp_every, min_gr
         got.append((g[0].left, g[0].right))
     assert got == sorted(got) and len(set(got)) == len(got)
     assert sub.render_text(ingroup, False) == tuple(amplicon.render(groups, ingroup, False))
+    # round 6: ONE slice of the result against the oracle at full size -- every window of the eight
+    # genomes whose left flank starts with these letters through tests/slice_oracle.py (numpy selection + the text oracle's
+    # merge tree and filter): the same lines, labels and multiplicities included, no group missing, none too many
+    from tests import slice_oracle
+    prefix = b"GATCA"
+    t4 = time.time()
+    want = slice_oracle.slice_lines([t for _, _, t in fam], labels, sorted(ingroup), L, D, R, prefix)
+    insl = (rows[:, :len(prefix)] == np.frombuffer(prefix, dtype=np.uint8)).all(axis=1)
+    part = amplicon.WindowGroups(rows[insl], hits["cand"][insl], hits["genome"][insl], labels, L, D, R)
+    got_lines = amplicon.merged_lines(part.groups())
+    assert sorted(got_lines) == sorted(want)
+    assert len(want) >= (8 * 100 if mu < 0.005 else 0)
     groups = ug
-    print(f"\nC3 (mu={mu:g}, {records} records, SNP per {snp_every}): {len(groups)} groups, dictL {sizes[0]} dictR {sizes[1]} groups before the filter {sizes[2]}; "
+    print(f"\nC3 slice {prefix.decode()}: {len(want)} lines of {len(set(ln.split(',')[0] + ln.split(',')[2] for ln in want))} groups "
+          f"equal the oracle's ({time.time() - t4:.0f} s of host time)")
+    print(f"C3 (mu={mu:g}, {records} records, SNP per {snp_every}): {len(groups)} groups, dictL {sizes[0]} dictR {sizes[1]} groups before the filter {sizes[2]}; "
           f"generation {t1 - t0:.0f} s, upload {t2 - t1:.0f} s, first wide run (with allocations) {t3 - t2:.1f} s")
 
 
