@@ -698,6 +698,8 @@ def main():
                                + ("" if args.no_collect else " + collect the candidate records (resident in HBM)"),
                        "kmers_per_step": kmers_total, "candidates": int(ncand), "records": int(records_total),
                        "place_tries": place_tries, "sort_lanes": lanes,
+                       # (the wide path: member windows the locate pass listed -- 16 bytes each -- or 0: a group number per window start)
+                       "wide_members_listed": int(eng.wide_fetch(_native.WIDE_LOCATED)[0]) if wide else None,
                        # which placement class the run got: probe times of the candidate pass-1 buffers, 800 MB
                        # each at configs[1] -- ~0.19 ms fast, ~0.22 / ~0.25 ms the slower classes; the fastest go to the lanes
                        "placement": eng.debug_place(),

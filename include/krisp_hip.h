@@ -249,6 +249,8 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
                                    carries the listed one's number with bit 31 set */
        KR_WIDE_BATCH_USED = 7,  /* u64 x 1: genomes per batch of the sort + intersect phases of the last run (0 = all at once): a genome set
                                    whose sorted keys do not fit the device goes through the phases in batches (kr_wide_run) */
+       KR_WIDE_LOCATED = 8,     /* u64 x 1: member windows the locate pass of the last run LISTED (round 6: a 16-byte entry per member
+                                   window instead of a group number per window start, when the members are few); 0 = the dense form ran */
        KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
                                    one-sector slot table in the last run, 0 = looked up through index + sorted keys,
                                    255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0), 254 = not built: with L = R the

@@ -608,6 +608,52 @@ def test_wide_spectra_with_the_packed_kernels_change_nothing(N, geo, monkeypatch
     assert d1 >= d0
 
 
+@pytest.mark.parametrize("geo,filt", [((12, 30, 12), True), ((32, 20, 32), False), ((40, 12, 36), True), ((20, 17, 9), True)])
+def test_wide_members_as_a_list_or_per_window_start_change_nothing(N, geo, filt, monkeypatch):
+    """Round 6: kr_wide_run's locate pass lists the member windows (16 bytes per member) when they are few, instead of a group
+    number per window start streamed twice more (k_wide_locate / k_wide_count_list / k_wide_emit_list).  The list
+    (default), the dense form (KR_WIDE_LOCLIST=0), a list too short for the members (KR_WIDE_LOCCAP: the run falls back
+    to the dense form by itself) and the dense form without the per-genome key cache (KR_WIDE_CACHE=0: a buffer of
+    its own) give the same hits; KR_WIDE_LOCATED says which form ran."""
+    L, D, R = geo
+    fam = _family(94, 4, 150_000)
+    rng = np.random.default_rng(11)
+    texts = []
+    for _, _, t in fam:
+        t = t.copy()
+        t[60_000:60_400] = t[20_000:20_400]                          # a repeat: groups with several members per genome
+        for p in rng.integers(0, len(t) - 50, size=10):
+            t[p:p + int(rng.integers(1, 20))] = ord("N")
+        texts.append(t)
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+
+    def run(env):
+        for k2 in ("KR_WIDE_LOCLIST", "KR_WIDE_LOCCAP", "KR_WIDE_CACHE"):
+            monkeypatch.delenv(k2, raising=False)
+        for k2, v in env.items():
+            monkeypatch.setenv(k2, v)
+        with N.Engine() as e:
+            e.set_params_wide(L, D, R, max_bases=max(len(t) for t in texts))
+            for i, t in enumerate(texts):
+                e.upload(i, t)
+            n = e.wide_run(ids, flags, apply_filter=filt)
+            hits = e.wide_fetch(N.WIDE_HITS)
+            hits = hits[np.lexsort((hits["strand"], hits["pos"], hits["genome"], hits["cand"]))]
+            n2 = e.wide_run(ids, flags, apply_filter=filt)             # (again in the same context: the buffers are there)
+            assert n2 == n
+            return n, hits.tobytes(), int(e.wide_fetch(N.WIDE_LOCATED)[0]), int(e.wide_fetch(N.WIDE_NGROUPS)[0])
+
+    n1, h1, loc1, g1 = run({})
+    n0, h0, loc0, g0 = run({"KR_WIDE_LOCLIST": "0"})
+    n2, h2, loc2, g2 = run({"KR_WIDE_LOCCAP": "7"})
+    n3, h3, loc3, g3 = run({"KR_WIDE_LOCLIST": "0", "KR_WIDE_CACHE": "0"})
+    n4, h4, loc4, g4 = run({"KR_WIDE_CACHE": "0"})
+    assert n1 > 0 and loc1 >= n1 // 2 and loc0 == 0 and loc2 == 0 and loc3 == 0 and loc4 == loc1
+    assert n1 == n0 == n2 == n3 == n4 and g1 == g0 == g2 == g3 == g4
+    assert h1 == h0 == h2 == h3 == h4
+
+
 def test_placement_tries_change_nothing_but_time(N, K):
     """KR_OPT_PLACE_TRIES: the pass-1 output buffer is chosen among several allocations (each timed under
     pass 1's write pattern); the result is the same as with a plain allocation"""
