@@ -251,6 +251,8 @@ enum { KR_WIDE_DICT_LEFT = 0,   /* u64: lefts present in all genomes, sorted (L 
                                    whose sorted keys do not fit the device goes through the phases in batches (kr_wide_run) */
        KR_WIDE_LOCATED = 8,     /* u64 x 1: member windows the locate pass of the last run LISTED (round 6: a 16-byte entry per member
                                    window instead of a group number per window start, when the members are few); 0 = the dense form ran */
+       KR_WIDE_KEYS_LISTED = 9, /* u64 x 1: composite keys the last run kept as per-genome LISTS (round 6: 16 bytes per window that has a key --
+                                   both flanks in the dictionaries -- instead of 16 bytes per window start, when such windows are few); 0 = dense */
        KR_WIDE_SLOT_BITS = 5 }; /* u64 x 7 (left pieces 0..2, right pieces 0..2, groups): bucket bits of the dictionary's
                                    one-sector slot table in the last run, 0 = looked up through index + sorted keys,
                                    255 = through minimizer buckets (KR_OPT_WIDE_ORDERED = 0), 254 = not built: with L = R the

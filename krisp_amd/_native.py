@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("KRISP_HIP_LIB") or os.path.join(HERE, "libkrisp_hip.s
 CAND = np.dtype([("prefix", "<u8"), ("in_mask", "<u8"), ("out_mask", "<u8")])
 RECORD = np.dtype([("key", "<u8"), ("genome", "<u4"), ("count", "<u4")])
 WIDE_HIT = np.dtype([("cand", "<u4"), ("genome", "<u4"), ("pos", "<u4"), ("strand", "<u4")])
-WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS, WIDE_SLOT_BITS, WIDE_NGROUPS, WIDE_BATCH_USED, WIDE_LOCATED = 0, 1, 2, 3, 4, 5, 6, 7, 8
+WIDE_DICT_LEFT, WIDE_DICT_RIGHT, WIDE_GROUPS, WIDE_HITS, WIDE_COUNTS, WIDE_SLOT_BITS, WIDE_NGROUPS, WIDE_BATCH_USED, WIDE_LOCATED, WIDE_KEYS_LISTED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 WIDE_MAX_K = 1024
 WIDE_MAX_FLANK = 256
 COMM_ID_BYTES = 128

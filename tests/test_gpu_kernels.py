@@ -654,6 +654,63 @@ def test_wide_members_as_a_list_or_per_window_start_change_nothing(N, geo, filt,
     assert h1 == h0 == h2 == h3 == h4
 
 
+@pytest.mark.parametrize("geo,filt,mu", [((32, 20, 32), True, 0.03), ((32, 60, 32), False, 0.03), ((20, 17, 20), True, 0.04),
+                                         ((32, 20, 32), True, 0.002)])
+def test_wide_composite_keys_as_lists_change_nothing(N, geo, filt, mu, monkeypatch):
+    """Round 6: where few window starts have a composite key (both flanks in the dictionaries) kr_wide_run keeps the keys of a
+    genome as a LIST -- 16 bytes per key, a segment per workgroup of k_hist8w; k_scatter1l and k_wide_locate_list walk it --
+    instead of 16 bytes per window start written once and streamed twice (Geom.wlcnt).  Lists (forced through
+    KR_WIDE_KEYFRAC, the share of window starts a segment is sized for: these genomes are too small and too close for
+    the default rule), the dense form (KR_WIDE_KEYLIST=0), segments too short (the run falls back to the dense form by
+    itself, from the genome that overflowed on), lists with the members per window start (KR_WIDE_LOCLIST=0: the keys
+    are made again), lists under key-space slices and in batches: the same hits; KR_WIDE_KEYS_LISTED says what ran."""
+    L, D, R = geo
+    from krisp_amd import synth
+    fam = synth.family(95, 2, 2, 300_000, records=4, mu=mu, snp_every=150)
+    texts = []
+    for _, _, t in fam:
+        t = t.copy()
+        t[70_000:70_300] = t[30_000:30_300]
+        texts.append(t)
+    flags = [f for _, f, _ in fam]
+    ids = list(range(len(fam)))
+    envs = ("KR_WIDE_KEYLIST", "KR_WIDE_KEYFRAC", "KR_WIDE_LOCLIST", "KR_SLICE_BASES", "KR_WIDE_BATCH", "KR_WIDE_LOCCAP")
+
+    def run(env):
+        for k2 in envs:
+            monkeypatch.delenv(k2, raising=False)
+        for k2, v in env.items():
+            monkeypatch.setenv(k2, v)
+        with N.Engine() as e:
+            e.set_params_wide(L, D, R, max_bases=max(len(t) for t in texts))
+            for i, t in enumerate(texts):
+                e.upload(i, t)
+            n = e.wide_run(ids, flags, apply_filter=filt)
+            hits = e.wide_fetch(N.WIDE_HITS)
+            hits = hits[np.lexsort((hits["strand"], hits["pos"], hits["genome"], hits["cand"]))]
+            listed = int(e.wide_fetch(N.WIDE_KEYS_LISTED)[0])
+            assert e.wide_run(ids, flags, apply_filter=filt) == n          # (again in the same context)
+            assert int(e.wide_fetch(N.WIDE_KEYS_LISTED)[0]) == listed
+            return n, hits.tobytes(), listed, int(e.wide_fetch(N.WIDE_NGROUPS)[0])
+
+    dense = run({"KR_WIDE_KEYLIST": "0"})
+    assert dense[0] > 0 and dense[2] == 0
+    sparse = mu >= 0.03
+    lists = run({"KR_WIDE_KEYFRAC": "0.12"})
+    assert lists[2] > 0 or not sparse                  # (close relatives: many starts have a key, segments may overflow)
+    forms = [lists,
+             run({"KR_WIDE_KEYFRAC": "0.0000001"}),                           # every segment 256 entries: too short, dense after all
+             run({"KR_WIDE_KEYFRAC": "0.12", "KR_WIDE_LOCLIST": "0"}),
+             run({"KR_WIDE_KEYFRAC": "0.12", "KR_WIDE_LOCCAP": "9"}),
+             run({"KR_WIDE_KEYFRAC": "0.12", "KR_SLICE_BASES": "1"}),
+             run({"KR_WIDE_KEYFRAC": "0.12", "KR_WIDE_BATCH": "2"}),
+             run({})]
+    for f in forms:
+        assert f[0] == dense[0] and f[3] == dense[3] and f[1] == dense[1]
+    if sparse:
+        assert forms[2][2] > 0 and forms[4][2] > 0 and forms[5][2] > 0
+
+
 def test_placement_tries_change_nothing_but_time(N, K):
     """KR_OPT_PLACE_TRIES: the pass-1 output buffer is chosen among several allocations (each timed under
     pass 1's write pattern); the result is the same as with a plain allocation"""
