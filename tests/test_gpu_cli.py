@@ -416,7 +416,7 @@ eng.close()
 
 @pytest.mark.parametrize("world,geo,filt", [(2, (30, 40, 30), True), (3, (30, 40, 30), True), (3, (40, 20, 36), True),
                                             (2, (20, 30, 20), False), (5, (32, 60, 32), True), (2, (30, 40, 30), "batch1"),
-                                            (2, (70, 12, 40), "batch2")])
+                                            (2, (70, 12, 40), "batch2"), (2, (30, 40, 30), "forms"), (3, (32, 60, 32), "forms")])
 def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
     """kr_wide_run with a communicator: 6 genomes of 1.5 Mbp (0.3 Mbp without the filter) sharded over `world` ranks (sharing cuda:0,
     file transport): the flank spectra and the group list are intersected over the ranks by the tree
@@ -432,7 +432,11 @@ def test_wide_run_over_several_ranks_equals_one_gpu(world, geo, filt, tmp_path):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), KR_ROOT=ROOT,
                    KR_COMM=str(tmp_path / "comm"), KR_L=str(geo[0]), KR_D=str(geo[1]), KR_R=str(geo[2]),
                    KR_FILTER="1" if filt else "0")
-        if isinstance(filt, str):           # (round 6: every rank's phases in batches of so many of ITS genomes)
+        if filt == "forms":
+            # (round 6: the ranks choose the forms of their lists by themselves -- here rank 0 keeps its composite keys as
+            # lists, rank 1 its member windows per window start, the others the defaults: no exchange may depend on it)
+            env.update({"KR_WIDE_KEYFRAC": "0.12"} if rank == 0 else ({"KR_WIDE_LOCLIST": "0"} if rank == 1 else {}))
+        elif isinstance(filt, str):         # (round 6: every rank's phases in batches of so many of ITS genomes)
             env["KR_WIDE_BATCH"] = filt[5:]
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
