@@ -213,6 +213,23 @@ WIDE_STAGE_BYTES = {
 }
 
 
+def wide_stage_bytes(key_share, member_share):
+    """Round 6: the same table for a run that kept its composite keys and its member windows as LISTS (DESIGN.md 3b;
+    kr_wide_fetch KR_WIDE_KEYS_LISTED / KR_WIDE_LOCATED): ONE look-up of the canonical flank per window start, 16 bytes
+    per KEY (key_share of the records have one) written by k_hist8w, read by pass 0 and by the locate pass, 16 bytes per
+    member window (member_share) written by the locate pass and read twice; the composite phase's sort passes move
+    key_share of what the dense model says."""
+    b = dict(WIDE_STAGE_BYTES)
+    b["hist8"] = 0.1875 + 8.0 + (0.1875 + 32 / 2 + 16.0 * key_share) + 8.0 + 8.0 * key_share
+    b["scatter1"] = (0.1875 + 8.0 + 16.0) + (16.0 + 8.0 + 16.0) * key_share
+    b["scatter2"] = 16.0 + 16.0 * key_share
+    b["localsort"] = 16.0 + 16.0 * key_share
+    b["hist2"] = 8.0 + 8.0 * key_share
+    b["intersect"] = 8.0 + 8.0 * key_share
+    b["locate"] = (16.0 + 32.0) * key_share + 3 * 16.0 * member_share
+    return b
+
+
 def cpu_baseline_wide(gen, L, D, R, per_gpu, mu, records, snp_every):
     """the reference's own text pipeline as restated in oracle/krisp_oracle.py (kstream -> sort -> merge tree ->
     filter -> render, pure Python, one core) on a down-scaled family of the same generator and geometry"""
@@ -440,6 +457,10 @@ def main():
             step()
         barrier()
         calib = {s: (v[0] / ncal, v[1] // ncal) for s, v in eng.stage_times().items() if v[1]}
+        if wide and int(eng.wide_fetch(_native.WIDE_KEYS_LISTED)[0]):
+            nrecords = max(int(sum(eng.wide_fetch(_native.WIDE_COUNTS))), 1)
+            stage_bytes_all = wide_stage_bytes(int(eng.wide_fetch(_native.WIDE_KEYS_LISTED)[0]) / nrecords,
+                                               int(eng.wide_fetch(_native.WIDE_LOCATED)[0]) / nrecords)
         dom_stage = max((s for s in calib if s in stage_bytes_all), key=lambda s: calib[s][0])
         eng.stage_select([dom_stage])
         eng.set_option(_native.OPT_LANES, lanes)
@@ -700,6 +721,7 @@ def main():
                        "place_tries": place_tries, "sort_lanes": lanes,
                        # (the wide path: member windows the locate pass listed -- 16 bytes each -- or 0: a group number per window start)
                        "wide_members_listed": int(eng.wide_fetch(_native.WIDE_LOCATED)[0]) if wide else None,
+                       "wide_keys_listed": int(eng.wide_fetch(_native.WIDE_KEYS_LISTED)[0]) if wide else None,
                        # which placement class the run got: probe times of the candidate pass-1 buffers, 800 MB
                        # each at configs[1] -- ~0.19 ms fast, ~0.22 / ~0.25 ms the slower classes; the fastest go to the lanes
                        "placement": eng.debug_place(),
