@@ -34,21 +34,37 @@ def _pack(rows):
     return out
 
 
+def _find(text, pat):
+    """positions i with text[i:i+len(pat)] == pat (len(pat) >= 4: the first four letters as one 32-bit compare per
+    position, over the four byte phases of the text)"""
+    n, m = len(text), len(pat)
+    assert m >= 4
+    w = np.uint32(int.from_bytes(bytes(pat[:4]), "little"))
+    hits = []
+    for o in range(4):
+        cnt = (n - o) // 4
+        if cnt > 0:
+            hits.append(np.flatnonzero(text[o:o + 4 * cnt].view("<u4") == w).astype(np.int64) * 4 + o)
+    p = np.sort(np.concatenate(hits)) if hits else np.empty(0, dtype=np.int64)
+    for j in range(4, m):
+        p = p[p + j < n]
+        p = p[text[p + j] == pat[j]]
+    return p
+
+
 def _starts(text, k, prefix, strand):
     """window starts p (forward coordinates) whose window -- text[p:p+k], or its reverse complement for strand 1 -- begins
     with `prefix` and lies inside one record"""
-    n = len(text)
-    m = len(prefix)
+    n, m = len(text), len(prefix)
     if n < k:
         return np.empty(0, dtype=np.int64)
-    ok = np.ones(n - k + 1, dtype=bool)
-    for j, ch in enumerate(prefix):
-        if strand == 0:
-            ok &= text[j:j + n - k + 1] == ch                          # window[j] = text[p + j]
-        else:
-            ok &= text[k - 1 - j:k - 1 - j + n - k + 1] == _COMP[ch]   # window[j] = comp(text[p + k - 1 - j])
-    p = np.flatnonzero(ok)
-    bad = np.flatnonzero(_CODE[text] == 255) if m < k else np.empty(0, dtype=np.int64)
+    if strand == 0:
+        p = _find(text, bytes(prefix))                                   # window[j] = text[p + j]
+    else:
+        rc = bytes(_COMP[np.frombuffer(bytes(prefix), dtype=np.uint8)][::-1])
+        p = _find(text, rc) + m - k                                      # window[j] = comp(text[p + k - 1 - j])
+    p = p[(p >= 0) & (p <= n - k)]
+    bad = np.flatnonzero(text == 10)
     if len(bad):
         p = p[np.searchsorted(bad, p) == np.searchsorted(bad, p + k)]
     return p
@@ -61,25 +77,32 @@ def _windows(text, p, k, strand):
     return rows
 
 
-def _flanks(text, p, k, L, R, strand, chunk=200_000):
-    lo = np.empty(len(p), dtype=np.uint64)
-    hi = np.empty(len(p), dtype=np.uint64)
-    for a in range(0, len(p), chunk):
-        rows = _windows(text, p[a:a + chunk], k, strand)
-        lo[a:a + chunk] = _pack(rows[:, :L])
-        hi[a:a + chunk] = _pack(rows[:, k - R:])
+def _flanks(text, p, k, L, R, strand):
+    """the packed left and right flank of every window (first letter in the top bits), a gather per column"""
+    lo = np.zeros(len(p), dtype=np.uint64)
+    hi = np.zeros(len(p), dtype=np.uint64)
+    comp = np.array([3, 2, 1, 0, 255], dtype=np.uint8)
+    code = _CODE.copy()
+    code[code == 255] = 4
+    for j in range(L):
+        c = code[text[p + j]] if strand == 0 else comp[code[text[p + k - 1 - j]]]
+        lo |= c.astype(np.uint64) << np.uint64(2 * (31 - j))
+    for j in range(R):
+        c = code[text[p + k - R + j]] if strand == 0 else comp[code[text[p + R - 1 - j]]]
+        hi |= c.astype(np.uint64) << np.uint64(2 * (31 - j))
     return lo, hi
 
 
 def slice_lines(texts, labels, ingroup, L, D, R, prefix, do_filter=True):
     """-> the lines of the reference's final (filtered) merged file whose left flank starts with `prefix` (bytes, <= L
     letters), for flanks of at most 32 letters each"""
-    assert 0 < L <= 32 and 0 < R <= 32 and 0 < len(prefix) <= L
+    assert 0 < L <= 32 and 0 < R <= 32 and 4 <= len(prefix) <= L
     k = L + D + R
     per = []
     for t in texts:
         t = np.frombuffer(bytes(t), dtype=np.uint8) if not isinstance(t, np.ndarray) else t
-        assert np.isin(np.unique(t), np.frombuffer(b"ACGT\n", dtype=np.uint8)).all(), "upper-case A C G T and newline only"
+        t = np.ascontiguousarray(t)
+        assert not np.isin(t, np.frombuffer(b"ACGT\n", dtype=np.uint8), invert=True).any(), "upper-case A C G T and newline only"
         ps, ls, rs, ss = [], [], [], []
         for strand in (0, 1):
             p = _starts(t, k, prefix, strand)
@@ -91,27 +114,22 @@ def slice_lines(texts, labels, ingroup, L, D, R, prefix, do_filter=True):
     for _, _, lo, _, _ in per:
         u = np.unique(lo)
         common = u if common is None else np.intersect1d(common, u, assume_unique=True)
-    pairs = None
+    # (a flank pair as ONE integer: rank of the left flank among the common ones x their number + rank of the right flank
+    # among all right flanks seen -- 64-bit compares instead of compares of pairs)
+    allr = np.unique(np.concatenate([hi[np.isin(lo, common)] for _, _, lo, hi, _ in per]))
     kept = []
+    pairs = None
     for t, p, lo, hi, s in per:
         sel = np.isin(lo, common)
         p, lo, hi, s = p[sel], lo[sel], hi[sel], s[sel]
-        kept.append((t, p, lo, hi, s))
-        pr = np.unique(np.stack([lo, hi], axis=1), axis=0)
-        if pairs is None:
-            pairs = pr
-        else:
-            both = np.concatenate([pairs, pr])
-            order = np.lexsort((both[:, 1], both[:, 0]))
-            both = both[order]
-            same = (both[1:] == both[:-1]).all(axis=1)
-            pairs = both[:-1][same]
-    pair_t = np.dtype([("l", "<u8"), ("r", "<u8")])
-    pairv = np.ascontiguousarray(pairs).view(pair_t).ravel()
+        code = np.searchsorted(common, lo).astype(np.int64) * np.int64(len(allr)) + np.searchsorted(allr, hi).astype(np.int64)
+        kept.append((t, p, code, s))
+        u = np.unique(code)
+        pairs = u if pairs is None else np.intersect1d(pairs, u, assume_unique=True)
     files = []
-    for (t, p, lo, hi, s), lab in zip(kept, labels):
+    for (t, p, code, s), lab in zip(kept, labels):
         lines = []
-        sel = np.isin(np.ascontiguousarray(np.stack([lo, hi], axis=1)).view(pair_t).ravel(), pairv)
+        sel = np.isin(code, pairs)
         for strand in (0, 1):
             q = p[sel & (s == strand)]
             for row in _windows(t, q, k, strand):

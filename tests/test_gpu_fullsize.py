@@ -259,7 +259,7 @@ def test_c3_eight_half_gbp_genomes_long_amplicons(mu, records, snp_every, min_gr
     one flank pair per group, a diagnostic column separates the groups).  Two inputs, named by their ids: SURVEY
     8(d)'s own generator (mu = 0.01, 16 records, a planted SNP per 10 kb: what `bench.py --config 2` times) and
     round 2's family of close relatives (mu = 0.001: ten times as many flanks survive the spectrum phase, > 10^5
-    groups to cut and render).  Round 6: one left-flank slice of the result (1/1024 of the key space) is compared with
+    groups to cut and render).  Round 6: one left-flank slice of the result (1/1024 of the key space; 1/16384 for the close relatives) is compared with
     the oracle line for line."""
     import time
     from krisp_amd import _native, amplicon, synth
@@ -317,14 +317,14 @@ def test_c3_eight_half_gbp_genomes_long_amplicons(mu, records, snp_every, min_gr
     # genomes whose left flank starts with these letters through tests/slice_oracle.py (numpy selection + the text oracle's
     # merge tree and filter): the same lines, labels and multiplicities included, no group missing, none too many
     from tests import slice_oracle
-    prefix = b"GATCA"
+    prefix = b"GATCA" if mu >= 0.005 else b"GATCAGT"      # (close relatives: 3 x 10^5 groups before the filter under five letters -- minutes of pure-Python merge tree)
     t4 = time.time()
     want = slice_oracle.slice_lines([t for _, _, t in fam], labels, sorted(ingroup), L, D, R, prefix)
     insl = (rows[:, :len(prefix)] == np.frombuffer(prefix, dtype=np.uint8)).all(axis=1)
     part = amplicon.WindowGroups(rows[insl], hits["cand"][insl], hits["genome"][insl], labels, L, D, R)
     got_lines = amplicon.merged_lines(part.groups())
     assert sorted(got_lines) == sorted(want)
-    assert len(want) >= (8 * 100 if mu < 0.005 else 0)
+    assert len(want) >= (100 if mu < 0.005 else 0)
     groups = ug
     print(f"\nC3 slice {prefix.decode()}: {len(want)} lines of {len(set(ln.split(',')[0] + ln.split(',')[2] for ln in want))} groups "
           f"equal the oracle's ({time.time() - t4:.0f} s of host time)")

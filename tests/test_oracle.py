@@ -136,8 +136,8 @@ def test_deduce_ldr():
     assert O.deduce_ldr(amplicon=50, conserved_left=10) is None
 
 
-@pytest.mark.parametrize("geo,prefix,do_filter", [((8, 10, 8), b"AC", True), ((12, 3, 5), b"G", True), ((6, 20, 9), b"TTA", False),
-                                                   ((32, 6, 32), b"C", True)])
+@pytest.mark.parametrize("geo,prefix,do_filter", [((8, 10, 8), b"ACGA", True), ((12, 3, 5), b"GTTC", True), ((6, 20, 9), b"TTAGG", False),
+                                                   ((32, 6, 32), b"CCAT", True)])
 def test_slice_oracle_equals_the_text_oracle_on_whole_genomes(geo, prefix, do_filter, tmp_path):
     """tests/slice_oracle.py (numpy selection of one left-flank prefix + this oracle's merge tree and filter: what the
     full-size long-amplicon test compares the device with) against this oracle run on the whole genomes, restricted to
@@ -146,7 +146,7 @@ def test_slice_oracle_equals_the_text_oracle_on_whole_genomes(geo, prefix, do_fi
     from tests import slice_oracle
     L, D, R = geo
     k = L + D + R
-    fam = synth.family(11, 2, 2, 30_000 if L < 32 else 60_000, records=3, mu=0.002, snp_every=400)
+    fam = synth.family(11, 2, 2, 50_000 if L < 32 else 100_000, records=3, mu=0.002, snp_every=400)
     files = []
     for name, _, text in fam:
         p = str(tmp_path / f"{name}.fa")
@@ -157,5 +157,5 @@ def test_slice_oracle_equals_the_text_oracle_on_whole_genomes(geo, prefix, do_fi
     want = O.filter_lines(merged, ingroup) if do_filter else merged
     want = [ln for ln in want if ln.startswith(prefix.decode())]
     got = slice_oracle.slice_lines([t for _, _, t in fam], [n for n, _, _ in fam], ingroup, L, D, R, prefix, do_filter)
-    assert len(want) > (0 if L == 32 else 5)
+    assert len(want) > 0
     assert sorted(got) == sorted(want)
