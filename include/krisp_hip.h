@@ -409,7 +409,7 @@ const char* kr_debug_copy_which(kr_ctx*);
  * threads per workgroup, log2(buckets per item) and 1 = 32-bit heads of the latest launch; out[5] = sort lanes in use
  * now; out[6..7] = intersections that left their late genomes to the probe, candidates the latest of them probed */
 /* 0 for a product build; else the result-changing experiment switches the library was compiled with (bit 0 -DKR_EXPERIMENTS,
- * 1 KR_ABLATE, 2 I3_ABL, 3 P2_ABL, 4 LS2_NORANK, 5 KR_EXP_NOLOOKUP: csrc/k_keys.inc).  No context, no GPU needed. */
+ * 1 KR_ABLATE, 2 I3_ABL, 3 P2_ABL, 4 LS2_NORANK, 5 KR_EXP_NOLOOKUP, 6 KR_EXP_MZONLY: csrc/k_keys.inc).  No context, no GPU needed. */
 int     kr_build_experiments(void);
 /* KR_OPT_LAZY_ORDER's counters: out[0] LDS sorts of whole slices kr_genome_sort left out, [1] made later (anchor, fetch, probe),
  * [2] kr_collect calls that read only the buckets their candidates touch, [3] the option's value, [4] intersection launches whose

@@ -353,7 +353,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
 
 
 def test_the_shipped_library_is_built_without_experiment_switches():
-    """the ablation / experiment macros (KR_ABLATE, I3_ABL, P2_ABL, LS2_NORANK, KR_EXP_NOLOOKUP: wrong
+    """the ablation / experiment macros (KR_ABLATE, I3_ABL, P2_ABL, LS2_NORANK, KR_EXP_NOLOOKUP, KR_EXP_MZONLY: wrong
     results, timing only) cannot reach the product: the library says which of them it was compiled with (none), the product
     build passes no -D at all, and a translation unit that defines one without -DKR_EXPERIMENTS does not compile"""
     import inspect
@@ -361,7 +361,7 @@ def test_the_shipped_library_is_built_without_experiment_switches():
     assert _native.load().kr_build_experiments() == 0
     assert "-D" not in inspect.getsource(kb.build)
     guard = open(os.path.join(ROOT, "krisp_amd", "csrc", "k_keys.inc")).read()
-    for macro in ("KR_ABLATE", "I3_ABL", "P2_ABL", "LS2_NORANK", "KR_EXP_NOLOOKUP"):
+    for macro in ("KR_ABLATE", "I3_ABL", "P2_ABL", "LS2_NORANK", "KR_EXP_NOLOOKUP", "KR_EXP_MZONLY"):
         assert macro in guard.split("#error", 1)[0], macro
     # every `#if(n)def` / `#if` on one of them lies in the sources the guard names: no sixth switch crept in
     import glob
@@ -369,7 +369,7 @@ def test_the_shipped_library_is_built_without_experiment_switches():
     seen = set()
     for f in glob.glob(os.path.join(ROOT, "krisp_amd", "csrc", "*")):
         seen |= set(pat.findall(open(f).read()))
-    assert seen <= {"KR_ABLATE", "I3_ABL", "P2_ABL", "LS2_NORANK", "KR_EXP_NOLOOKUP"}, seen
+    assert seen <= {"KR_ABLATE", "I3_ABL", "P2_ABL", "LS2_NORANK", "KR_EXP_NOLOOKUP", "KR_EXP_MZONLY"}, seen
 
 
 def test_missing_library_fails_loudly(monkeypatch):
