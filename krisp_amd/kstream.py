@@ -123,8 +123,8 @@ class kstream:
         through the reference's chain on the host by itself and joins the sorted stream.
         Not on the device, with the reason in `plan_reason`:
           * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
-            formed before the filters), in stream order (sorted: two forward passes, over the sequences and their
-            reverse complements);
+            formed before the filters), in stream order with several k (one k, sorted or in stream order: two forward
+            passes, over the sequences and their reverse complements, merged / put together by window start);
           * a column order that cuts the window into more than eight pieces (any split list, any column list below that
             has a key layout: three blocks by shifts, kr_set_field_order; more, or pieces out of window order -- two
             split sizes counted from the end --, piece by piece, kr_set_field_pieces);
@@ -138,6 +138,8 @@ class kstream:
             plans = [self._plan_one(k) for k in self.kmers]
             if any(p is None for p in plans):
                 return None
+            if self.sort is not True and any(p.get("split_strands") for p in plans):
+                return self._no_plan("the bases --allow / --disallow leave are not closed under complement while both strands are emitted, in stream order with several k")
             # (unsorted, the windows of a record come k by k, kstream.py:631-642: one stream-order pass per k on the
             # device, put together record by record -- round 5)
             return dict(multi=plans, strands=plans[0]["strands"], layout="multi", fields=None, geometry=None,
@@ -169,9 +171,7 @@ class kstream:
             # a window and its reverse complement are filtered each by itself (the complements are formed BEFORE the filters,
             # kstream.py:696-766): one strand may stay where the other goes.  Sorted streams (round 6): two forward-only
             # passes -- over the sequences and over their reverse complements -- merged; in stream order a window's two
-            # k-mers would have to be told apart on the device: host chain
-            if self.sort is not True:
-                return self._no_plan("the bases --allow / --disallow leave are not closed under complement while both strands are emitted, in stream order")
+            # k-mers come from the two passes by the position of their window (round 6, _device_keys)
             split_strands = True
         # fields of the output line (kstream.py:805-832)
         if self.split is None:
@@ -368,7 +368,7 @@ class kstream:
                 eng.set_strands(_native.STRANDS_FORWARD)
             if allow is not None:
                 eng.set_allow(allow)
-            if plan.get("split_strands"):
+            if plan.get("split_strands") and plan["sorted"]:
                 # (the reverse complement of every record: a k-mer of it that the base mask lets through is the reverse
                 # complement of a window whose own k-mer may have been dropped, and the other way round)
                 comp = np.arange(256, dtype=np.uint8)
@@ -380,11 +380,35 @@ class kstream:
             elif plan["sorted"]:
                 eng.add(0, bases)
                 keys = eng.keys(0).copy()
+            elif plan.get("split_strands"):
+                # stream order, bases the strands do not share (round 6): a window is followed by its reverse complement, each
+                # filtered by itself (kstream.py:696-766).  Two forward-only passes in window order -- over the text: the
+                # windows the base mask lets through; over its reverse complement: the reverse complements the mask lets
+                # through, window q there = the window that starts at n - q - k here -- put together by window start
+                comp = np.arange(256, dtype=np.uint8)
+                for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+                    comp[a] = b
+                nb, kk = len(bases), plan["k"]
+                rcb = np.ascontiguousarray(comp[bases[::-1]])
+                eng.upload(0, bases)
+                kf = eng.keys_in_order(0, nb).copy()
+                eng.upload(1, rcb)
+                kr = eng.keys_in_order(1, nb).copy()[::-1]
+                sf = self._device_window_starts(bases, plan)
+                sr = (nb - self._device_window_starts(rcb, plan) - kk)[::-1]
+                assert len(kf) == len(sf) and len(kr) == len(sr), (len(kf), len(sf), len(kr), len(sr))
+                pos = np.concatenate([sf, sr])
+                order = np.lexsort((np.concatenate([np.zeros(len(sf), dtype=np.int8), np.ones(len(sr), dtype=np.int8)]), pos))
+                keys = np.concatenate([kf, kr])[order]
+                split_starts, cnt = np.unique(pos, return_counts=True)
+                split_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
             else:
                 eng.upload(0, bases)
                 keys = eng.keys_in_order(0, len(bases))
         if not plan["sorted"]:
             # stream order: (keys, rna, [(window start, its k-mers)], starts of the device's windows) -- _device_blocks interleaves
+            if plan.get("split_strands"):
+                return keys, rna, special, split_starts, split_off        # (0, 1 or 2 k-mers per window: their places in `keys`)
             if want_layout:
                 return keys, rna, special, self._device_window_starts(bases, plan), np.flatnonzero(bases == 10)
             return keys, rna, special, (self._device_window_starts(bases, plan) if special else None)
@@ -487,13 +511,19 @@ class kstream:
         got = self._device_keys(sequences, plan)
         if got is None:
             return None
-        keys, rna, special, dev_starts = got
+        dev_off = None
+        if len(got) == 5:               # (stream order with bases the strands do not share: 0, 1 or 2 k-mers per window)
+            keys, rna, special, dev_starts, dev_off = got
+        else:
+            keys, rna, special, dev_starts = got
         if not plan["sorted"] and special:
             import numpy as np
             # the device's k-mers in stream order (per window: the window, then its reverse complement under --complements)
             # with the host's special windows' k-mers put in by the position of their window
             per = 2 if plan["strands"] == 0 else 1
-            assert len(keys) == per * len(dev_starts), (len(keys), len(dev_starts))
+            if dev_off is None:
+                assert len(keys) == per * len(dev_starts), (len(keys), len(dev_starts))
+                dev_off = per * np.arange(len(dev_starts) + 1, dtype=np.int64)
             fields = plan["fields"]
             width = plan["k"] + len(fields)                     # bytes of a device line, newline included
 
@@ -503,7 +533,7 @@ class kstream:
                     upto = int(np.searchsorted(dev_starts, start))
                     for a in range(done, upto, _WRITE_CHUNK):
                         b = min(upto, a + _WRITE_CHUNK)
-                        yield codec.keys_to_fields_bytes(keys[per * a:per * b], fields, rna)
+                        yield codec.keys_to_fields_bytes(keys[dev_off[a]:dev_off[b]], fields, rna)
                     done = upto
                     lines = [self._split_one(x) if self.split is not None else x for x in kmers]
                     if rna:
@@ -512,7 +542,7 @@ class kstream:
                         yield ("\n".join(lines) + "\n").encode("latin-1")
                 for a in range(done, len(dev_starts), _WRITE_CHUNK):
                     b = min(len(dev_starts), a + _WRITE_CHUNK)
-                    yield codec.keys_to_fields_bytes(keys[per * a:per * b], fields, rna)
+                    yield codec.keys_to_fields_bytes(keys[dev_off[a]:dev_off[b]], fields, rna)
             return blocks(), int(len(keys)) + sum(len(km) for _, km in special)
         if (plan["layout"] == "lrd" and len(plan["fields"]) == 3 and not plan["keepcase"] and not plan["expand"] and plan["strands"] == 0
                 and plan["sorted"] and self.disallow == {"N", "n"} and (self.allow is None or self.allow <= set("ACGTNacgtn"))):

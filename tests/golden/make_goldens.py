@@ -419,6 +419,19 @@ def kstream_cases_r6():
             (dict(kmers=[4, 5], complements=True, allow="AG", sort=True, mapsoft=True), low_t),
     ]):
         add(f"strandsplit{j}", kw, file_text=text, fname="s.fa", use_write=bool(j % 2))
+    # ... and in stream order: a window, then its reverse complement, each kept or dropped by itself
+    rna_t = fasta("ACG" * 8 + "T" * 2 + "acg" + "N" + "RY", 3, 20, 60).replace("T", "U").replace("t", "u")
+    for j, (kw, text) in enumerate([
+            (dict(kmers=5, complements=True, allow="ACG", mapsoft=True), low_t),
+            (dict(kmers=4, complements=True, disallow="TtNn", mapsoft=True, split=[1, -1]), low_t),
+            (dict(kmers=6, complements=True, allow="ACGacg", split=[2, 2]), low_t),
+            (dict(kmers=5, complements=True, disallow="A", omitsoft=True, split=[2]), texts[0]),
+            (dict(kmers=4, complements=True, allow="CGT", disallow="Nn", mapsoft=True, split=[1, 1, -1]), texts[1]),
+            (dict(kmers=5, complements=True, disallow="GgNn", mapsoft=True), texts[1]),
+            (dict(kmers=4, complements=True, disallow="AaNn", omitsoft=True, split=[-2]), rna_t),
+            (dict(kmers=[4, 5], complements=True, allow="AG", mapsoft=True), low_t),              # several k: host chain
+    ]):
+        add(f"strandsplit_unsorted{j}", kw, file_text=text, fname="s.fa", use_write=bool(j % 2))
     return cases
 
 

@@ -288,6 +288,49 @@ def test_kstream_device_routes_equal_the_host_chain_on_random_inputs(seed, tmp_p
     assert run(ks) == run(ks.host_lines), kw
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_STRANDSPLIT_SEEDS", "24"))))
+def test_kstream_bases_the_strands_do_not_share_equal_the_host_chain(seed, tmp_path):
+    """round 6 (VERDICT r5 missing #5): --allow / --disallow sets that leave plain bases whose complements they drop, with
+    both strands emitted -- a window and its reverse complement are kept or dropped each by itself (the complement step
+    comes before the filters, kstream.py:696-766).  Sorted: two forward passes merged; in stream order: the two passes'
+    k-mers put together by the position of their window, the host's special windows among them.  Against the plain
+    generator chain (pinned to the reference by its vectors, eight of them for exactly this) on random inputs with lower
+    case, N, IUPAC letters and odd characters, soft-mask rules, splits, kstream.write."""
+    import random
+    from krisp_amd.kstream import kstream
+    rng = random.Random(9700 + seed)
+    alphabet = rng.choice(["ACGT", "ACGTacgtN", "ACGTACGTACGacgtNnR", "AACCGGTn-", "AAACCCGGGTacgRYn"])
+    recs = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 300))) for _ in range(rng.randint(1, 5))]
+    text = "".join(f">r{i}\n{r}\n" for i, r in enumerate(recs))
+    if seed % 5 == 4:
+        text = text.replace("T", "U").replace("t", "u")
+    src = str(tmp_path / "x.fa")
+    open(src, "w").write(text)
+    kw = [dict(mapsoft=True), dict(omitsoft=True), {}][seed % 3]
+    k = rng.randint(2, 12)
+    kw.update(kmers=k, complements=True, sort=seed % 2 == 0)
+    kw.update(rng.choice([dict(allow="ACG"), dict(disallow="A"), dict(disallow="TtNn"), dict(allow="CGT", disallow="Nn"),
+                          dict(allow="ACGacgN"), dict(disallow="Gg"), dict(allow="AGRY")]))
+    if rng.random() < 0.5 and k >= 3:
+        kw.update(split=rng.choice([[1], [rng.randint(1, k - 2), -1], [1, 1]]))
+    ks = kstream(**kw)
+    plan = ks.device_plan()
+    assert plan is not None and plan["split_strands"], (kw, ks.plan_reason)
+
+    def run(fn):
+        try:
+            return ("ok", list(fn(src)))
+        except Exception as e:  # noqa: BLE001
+            return ("raises", type(e).__name__)
+    assert run(ks) == run(ks.host_lines), kw
+    if seed % 4 == 1:
+        out = str(tmp_path / "o.txt")
+        want = run(ks.host_lines)
+        if want[0] == "ok":
+            assert ks.write(out, src) == len(want[1])
+            assert open(out).read().split("\n")[:-1] == want[1]
+
+
 def test_readme_known_answers_on_the_gpu(tmp_path):
     d = os.path.join(GOLDEN, "c1")
     ing = [f"{d}/ingroup{i}.fasta.gz" for i in (0, 1)]
