@@ -122,9 +122,6 @@ class kstream:
         anything else that the chain would keep -- IUPAC letters, lower case under 'neither', other characters -- runs
         through the reference's chain on the host by itself and joins the sorted stream.
         Not on the device, with the reason in `plan_reason`:
-          * --allow / --disallow sets that leave a set of plain bases both strands do not share (the complement is
-            formed before the filters), in stream order with several k (one k, sorted or in stream order: two forward
-            passes, over the sequences and their reverse complements, merged / put together by window start);
           * a column order that cuts the window into more than eight pieces (any split list, any column list below that
             has a key layout: three blocks by shifts, kr_set_field_order; more, or pieces out of window order -- two
             split sizes counted from the end --, piece by piece, kr_set_field_pieces);
@@ -138,8 +135,6 @@ class kstream:
             plans = [self._plan_one(k) for k in self.kmers]
             if any(p is None for p in plans):
                 return None
-            if self.sort is not True and any(p.get("split_strands") for p in plans):
-                return self._no_plan("the bases --allow / --disallow leave are not closed under complement while both strands are emitted, in stream order with several k")
             # (unsorted, the windows of a record come k by k, kstream.py:631-642: one stream-order pass per k on the
             # device, put together record by record -- round 5)
             return dict(multi=plans, strands=plans[0]["strands"], layout="multi", fields=None, geometry=None,
@@ -408,7 +403,10 @@ class kstream:
         if not plan["sorted"]:
             # stream order: (keys, rna, [(window start, its k-mers)], starts of the device's windows) -- _device_blocks interleaves
             if plan.get("split_strands"):
-                return keys, rna, special, split_starts, split_off        # (0, 1 or 2 k-mers per window: their places in `keys`)
+                # (0, 1 or 2 k-mers per window: their places in `keys`)
+                if want_layout:
+                    return keys, rna, special, split_starts, np.flatnonzero(bases == 10), split_off
+                return keys, rna, special, split_starts, split_off
             if want_layout:
                 return keys, rna, special, self._device_window_starts(bases, plan), np.flatnonzero(bases == 10)
             return keys, rna, special, (self._device_window_starts(bases, plan) if special else None)
@@ -432,10 +430,14 @@ class kstream:
                 got = self._device_keys(sequences, sub, want_layout=True)
                 if got is None:
                     return None
-                keys, rna, special, starts, seps = got
                 per = 2 if sub["strands"] == 0 else 1
-                assert len(keys) == per * len(starts), (len(keys), len(starts))
-                passes.append((sub, keys, list(special), starts, per))
+                if len(got) == 6:           # (bases the strands do not share: 0, 1 or 2 k-mers per window)
+                    keys, rna, special, starts, seps, off = got
+                else:
+                    keys, rna, special, starts, seps = got
+                    assert len(keys) == per * len(starts), (len(keys), len(starts))
+                    off = per * np.arange(len(starts) + 1, dtype=np.int64)
+                passes.append((sub, keys, list(special), starts, off))
                 total += int(len(keys)) + sum(len(km) for _, km in special)
             bounds = np.concatenate([[-1], seps, [np.iinfo(np.int64).max]]).astype(np.int64)
 
@@ -443,7 +445,7 @@ class kstream:
                 sp_at = [0] * len(passes)
                 for r in range(len(bounds) - 1):
                     lo_pos, hi_pos = int(bounds[r]) + 1, int(bounds[r + 1])            # the record's characters [lo_pos, hi_pos)
-                    for pi, (sub, keys, special, starts, per) in enumerate(passes):
+                    for pi, (sub, keys, special, starts, off) in enumerate(passes):
                         a = int(np.searchsorted(starts, lo_pos))
                         b = int(np.searchsorted(starts, hi_pos))
                         while True:
@@ -452,7 +454,7 @@ class kstream:
                             upto = b if nxt is None else int(np.searchsorted(starts, nxt[0]))
                             for x in range(a, upto, _WRITE_CHUNK):
                                 y = min(upto, x + _WRITE_CHUNK)
-                                yield codec.keys_to_fields_bytes(keys[per * x:per * y], sub["fields"], rna)
+                                yield codec.keys_to_fields_bytes(keys[off[x]:off[y]], sub["fields"], rna)
                             a = upto
                             if nxt is None:
                                 break

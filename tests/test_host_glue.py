@@ -180,12 +180,12 @@ def test_kstream_routes_only_the_krisp_fasta_combination_to_the_device():
     p = kstream(**dict(base, sortcols=[2, 1])).device_plan()
     assert p["layout"] == "custom" and p["order"] == [2, 1, 0]
     # round 6: bases both strands do not share -- two forward passes (split_strands), merged (sorted) or put together by
-    # window start (stream order); several k in stream order: host chain
+    # window start (stream order, one k or several)
     for change in (dict(allow="ACG"), dict(disallow="A"), dict(allow="ACG", sort=False), dict(disallow="A", sort=False)):
         p = kstream(**dict(base, **change)).device_plan()
         assert p is not None and p["split_strands"] and p["strands"] == 0, change
-    for change, why in ((dict(allow="ACG", sort=False, kmers=[27, 28]), "closed under complement"),
-                        (dict(kmers=40, split=[30, -2], complements=False), "outside the krisp_fasta combination"),
+    assert all(q["split_strands"] for q in kstream(**dict(base, allow="ACG", sort=False, kmers=[27, 28])).device_plan()["multi"])
+    for change, why in ((dict(kmers=40, split=[30, -2], complements=False), "outside the krisp_fasta combination"),
                         (dict(kmers=1100, split=[30, -2]), "k > 1024"), (dict(kmers=620, split=[270, -2]), "flanks outside"),
                         (dict(kmers=40, split=[30, -2], sort=False), "k > 32 without --sort")):
         ks = kstream(**dict(base, **change))
