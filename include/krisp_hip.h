@@ -297,6 +297,15 @@ int64_t kr_ingest_file(const char* path, uint8_t** bases, int64_t* stats);
  *                           Returns the number of bases (separators included).
  *   kr_genome_fetch_bases   an uploaded genome's bases back to the host (the IUPAC side channel, text cutting) */
 int64_t kr_read_file(const char* path, uint8_t** text, int64_t* stats);
+/* Round 6 -- a BGZF file (bgzip: a chain of gzip members of <= 64 KB of text that say
+ * how long they are) inflated ON THE DEVICE, a lane per member (csrc/k_inflate.inc), then parsed there as
+ * kr_genome_upload_text parses a text (.gz streams: no universal newlines): `file` = the bytes of the file as they lie on
+ * disk.  Every member's CRC-32 and ISIZE are checked on the device.  Returns the number of bases; KR_ERR_HOST -- nothing
+ * uploaded -- when the file is not BGZF all the way (plain gzip, other extra fields, >= 2^32 bytes) or a member does not
+ * inflate to its trailer: the caller then reads the file as any other `.gz` (kr_read_file), and that path's verdict on it
+ * stands (the reference: kstream.py:458-479, gzip.open).  stats[8]: [0..3] as kr_genome_upload_text, [4] members,
+ * [5] first bad member, [6] its status, [7] microseconds of the inflate + CRC kernels. */
+int64_t kr_genome_upload_bgzf(kr_ctx*, int id, const uint8_t* file, size_t n, int one_shot, int64_t* stats);
 /* The large device buffers of `n` genomes (ids[]) of up to n_bases bases each -- upload buffer, sorted-key arrays, sort
  * lanes; with_text: the device reader's copy of the file text as well -- made ahead of the uploads, while host threads
  * still read and inflate the files (krisp_fasta.py:86-123 starts a process per genome; here the one context gets its

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("kr_ingest_file", _c.c_int64, [_c.c_char_p, _P, _P]),
     ("kr_read_file", _c.c_int64, [_c.c_char_p, _P, _P]),
     ("kr_genome_upload_text", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t, _c.c_int, _c.c_int, _P]),
+    ("kr_genome_upload_bgzf", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t, _c.c_int, _P]),
     ("kr_reserve", _c.c_int, [_P, _P, _c.c_int, _c.c_size_t, _c.c_int]),
     ("kr_genome_fetch_bases", _c.c_int64, [_P, _c.c_int, _P, _c.c_size_t]),
     ("kr_host_free", None, [_P]),
@@ -381,6 +382,20 @@ class Engine:
         n = self._check(self.lib.kr_genome_upload_text(self.ctx, gid, _ptr(t), len(t), 1 if universal_newlines else 0,
                                                        1 if one_shot else 0, _ptr(stats)), "kr_genome_upload_text")
         return n, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3])
+
+    def upload_bgzf(self, gid, raw, one_shot=True):
+        """the bytes of a BGZF file -> genome gid: inflated on the device, a lane per member, every member checked against
+        its CRC-32 and length, then parsed there (kr_genome_upload_bgzf).  Returns (bases, records, special characters, rna,
+        fasta, members, microseconds of the inflate kernels), or None when the file is not BGZF all the way or a member
+        does not inflate to its trailer: nothing is uploaded then, the caller reads the file as any other .gz."""
+        t = np.ascontiguousarray(raw, dtype=np.uint8)
+        stats = np.zeros(8, dtype=np.int64)
+        n = self.lib.kr_genome_upload_bgzf(self.ctx, gid, _ptr(t), len(t), 1 if one_shot else 0, _ptr(stats))
+        if n == ERR_HOST:
+            self.last_bgzf = (int(stats[4]), int(stats[5]), int(stats[6]), self.lib.kr_last_error(self.ctx).decode())
+            return None
+        n = self._check(n, "kr_genome_upload_bgzf")
+        return n, int(stats[0]), int(stats[1]), stats[2] == 1, bool(stats[3]), int(stats[4]), int(stats[7])
 
     def reserve(self, ids, n_bases, with_text=False):
         """the large device buffers of genomes `ids` of up to n_bases bases, ahead of their uploads (kr_reserve)"""

@@ -40,6 +40,7 @@
 #include "k_intersect3.inc"  // the same intersection as a persistent, software-pipelined kernel (items of whole buckets)
 #include "k_intersect3t.inc" // ... with 32-bit heads where the geometry allows
 #include "k_text.inc"        // the reference reader on the device: file text -> upload buffer
+#include "k_inflate.inc"     // BGZF members inflated on the device, a lane per member (round 6)
 #include "k_wide.inc"        // wide path kernels, copy kernel
 
 #include "h_core.inc"        // context, buffers, parameters, upload, sort, finalize   (opens extern "C")

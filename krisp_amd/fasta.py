@@ -14,6 +14,7 @@ The output is what kr_genome_upload takes: ASCII bases, '\\n' between records.
 import bz2
 import gzip
 import os
+import time
 
 import numpy as np
 
@@ -97,10 +98,45 @@ def load_bases(filename):
     return bases, bool(rna), nspecial
 
 
+class BgzfFile:
+    """a BGZF file as read_text hands it to ingest_on_device: the bytes as they lie on disk (`raw`) -- the device inflates
+    them, a lane per member (kr_genome_upload_bgzf) --, len() = the bytes of text the members' trailers promise"""
+
+    def __init__(self, filename, raw, text_bytes):
+        self.filename, self.raw, self.text_bytes = filename, raw, text_bytes
+
+    def __len__(self):
+        return self.text_bytes
+
+    def inflate(self):
+        """the text through the host path (read_text with the device inflate off)"""
+        return _read_text_host(self.filename)[0]
+
+
+# KRISP_DEVICE_INFLATE=0: BGZF files through the host inflate as before round 6 (A/B, tests)
+def device_inflate_on():
+    return os.environ.get("KRISP_DEVICE_INFLATE", "1") != "0"
+
+
 def read_text(filename):
     """file -> (its text, universal_newlines): read + inflate only -- inside the library into pinned memory
     (kr_read_file) where it takes the file, else through Python's gzip / bz2.  The parse is left to the device
-    (ingest_on_device)."""
+    (ingest_on_device).  Round 6: a `.gz` file that is BGZF all the way (bgzip: members that say how long they are) is only
+    READ here -- BgzfFile --: the device inflates it (kr_genome_upload_bgzf)."""
+    if os.path.splitext(filename)[1] == ".gz" and device_inflate_on():
+        size = os.path.getsize(filename)
+        if 28 <= size < (1 << 32) - 64:
+            tb = _bgzf_text_bytes(filename, size)
+            if tb is not None and tb < DEVICE_TEXT_MAX:
+                t0 = time.time()
+                raw = np.fromfile(filename, dtype=np.uint8)
+                LAST_TIMINGS[os.fspath(filename)] = dict(read_s=time.time() - t0, inflate_s=0.0, parse_s=0.0, members=0,
+                                                         libdeflate=False, device_inflate=True)
+                return BgzfFile(os.fspath(filename), raw, tb), False
+    return _read_text_host(filename)
+
+
+def _read_text_host(filename):
     from . import _native
     ext = os.path.splitext(filename)[1]
     got = _native.read_file(filename)           # (None: a .bz2 file on a box without libbz2)
@@ -171,6 +207,18 @@ def ingest_on_device(eng, gid, text, universal, k, omit_soft):
     """text of a sequence file -> genome gid of `eng`, parsed on the device with the reference reader's semantics
     (kr_genome_upload_text; the host never sees the bases unless the genome holds characters outside ACGTNacgtn:
     then they come back for the side channel of ingest()).  Returns (bases on the device, is_rna, IUPAC k-mers)."""
+    if isinstance(text, BgzfFile):
+        got = eng.upload_bgzf(gid, text.raw, one_shot=True)
+        if got is not None:
+            n, _nrec, nspecial, rna, _fasta, members, us = got
+            tm = LAST_TIMINGS.get(text.filename)
+            if tm is not None:
+                tm.update(members=members, device_inflate_s=us * 1e-6)
+            special = scan_special(eng.fetch_bases(gid, n), k, omit_soft) if nspecial else []
+            return n, bool(rna), special
+        # (not BGZF all the way after all, or a member that does not inflate to its trailer: the host path, whose verdict
+        # on the file -- Python's gzip errors included -- stands)
+        text = text.inflate()
     if len(text) >= DEVICE_TEXT_MAX:
         # the device's reader indexes its text with 32 bits: a longer text (a genome of more than 4.29e9 bases: the packed
         # path takes them up to 2^33) is parsed by the library's host parser, same result (tests compare the two)

@@ -711,6 +711,138 @@ def test_wide_composite_keys_as_lists_change_nothing(N, geo, filt, mu, monkeypat
         assert forms[2][2] > 0 and forms[4][2] > 0 and forms[5][2] > 0
 
 
+def _bgzf(data, block=65280, level=6, strategy=0, eof=True):
+    """bytes -> a BGZF file as bgzip writes it: gzip members of `block` bytes of text with the BC extra field"""
+    import struct
+    import zlib
+    out = []
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof else [])
+    for ch in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        cd = co.compress(ch) + co.flush()
+        bsize = len(cd) + 26
+        assert bsize <= 65536
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + cd
+                   + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))
+    return b"".join(out)
+
+
+def _fasta_text(seed, n, alphabet=b"ACGT", width=80, nrec=3, lower=True, nruns=True):
+    rng = np.random.default_rng(seed)
+    a = np.frombuffer(alphabet, dtype=np.uint8)
+    recs = []
+    for r in range(nrec):
+        s = a[rng.integers(0, len(a), size=n // nrec)].copy()
+        if nruns:
+            p = int(rng.integers(0, max(1, len(s) - 500)))
+            s[p:p + 400] = ord("N")
+        if lower:
+            p = int(rng.integers(0, max(1, len(s) - 300)))
+            s[p:p + 200] |= 0x20
+        body = b"\n".join(bytes(s[i:i + width]) for i in range(0, len(s), width))
+        recs.append(b">rec%d some words\n" % r + body + b"\n")
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("what", ["fasta_l6", "fasta_l1", "fasta_l9", "stored", "fixed", "tiny_blocks", "random_bytes", "runs", "iupac",
+                                  "empty", "one_byte", "no_eof", "rna"])
+def test_bgzf_inflated_on_the_device_equals_the_host_path(N, what):
+    """Round 6: kr_genome_upload_bgzf -- every member of a BGZF file a lane of k_bgzf_inflate (stored,
+    fixed and dynamic blocks; copies over the lane's own output; CRC-32 and ISIZE checked on the device), then the
+    device's reader -- against kr_genome_upload_text over the text Python's gzip module gives (the reference's reader,
+    kstream.py:458-479): the same bases, records, special characters and alphabet.  Compression levels 0 / 1 / 6 / 9, fixed
+    Huffman codes only, members of 100 bytes, bytes of every value (the codes of a dynamic block at their widest; the
+    parser then sees one long line of odd characters), runs (distance 1, length 258), IUPAC letters, an empty file, one
+    byte, no EOF member, RNA."""
+    import gzip
+    import zlib
+    kw = {}
+    if what.startswith("fasta"):
+        text, kw = _fasta_text(1, 400_000), dict(level=int(what[-1]))
+    elif what == "stored":
+        text, kw = _fasta_text(2, 200_000), dict(level=0, block=60000)
+    elif what == "fixed":
+        text, kw = _fasta_text(3, 200_000), dict(strategy=zlib.Z_FIXED)
+    elif what == "tiny_blocks":
+        text, kw = _fasta_text(4, 30_000), dict(block=100)
+    elif what == "random_bytes":
+        text = b">r\n" + bytes(np.random.default_rng(5).integers(0, 256, size=300_000, dtype=np.uint8))
+        kw = dict(block=40000)
+    elif what == "runs":
+        text = b">r\n" + b"A" * 200_000 + b"\n" + b"ACGT" * 30_000 + b"\n>s\n" + b"N" * 70_000 + b"\n"
+    elif what == "iupac":
+        text = _fasta_text(6, 100_000, alphabet=b"ACGTACGTACGTRYKMSWN")
+    elif what == "empty":
+        text = b""
+    elif what == "one_byte":
+        text = b"A"
+    elif what == "no_eof":
+        text, kw = _fasta_text(7, 150_000), dict(eof=False)
+    else:
+        text = _fasta_text(8, 150_000).replace(b"T", b"U").replace(b"t", b"u")
+    raw = _bgzf(text, **kw)
+    assert gzip.decompress(raw) == text
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=max(len(text), 64))
+        got = e.upload_bgzf(0, np.frombuffer(raw, dtype=np.uint8))
+        assert got is not None, e.last_bgzf
+        n, nrec, nspecial, rna, fasta, members, us = got
+        bases = e.fetch_bases(0, n).copy()
+        n2, nrec2, nspecial2, rna2, fasta2 = e.upload_text(1, np.frombuffer(text, dtype=np.uint8), False)
+        assert (n, nrec, nspecial, rna, fasta) == (n2, nrec2, nspecial2, rna2, fasta2)
+        assert np.array_equal(bases, e.fetch_bases(1, n2))
+        assert members == len(raw) and members == 0 or members >= 1
+        if n:
+            e.sort(0)
+            e.sort(1)
+            assert e.count(0) == e.count(1)
+
+
+def test_bgzf_members_that_do_not_inflate_to_their_trailers_go_to_the_host(N):
+    """A damaged BGZF file: the device says so for every kind of damage -- a flipped byte in a member's data (an invalid
+    code, a distance before the member's start, a wrong length, a CRC mismatch at the latest), in its CRC, in its ISIZE,
+    a member cut short, a header that is not BGZF, plain gzip -- and uploads nothing; 300 single-byte flips anywhere in
+    the file never do anything else than that or (a flip in a header's time stamp or OS byte) inflate to the same text."""
+    import gzip
+    text = _fasta_text(11, 300_000)
+    raw = bytearray(_bgzf(text, block=30000))
+    plain = np.frombuffer(text, dtype=np.uint8)
+    rng = np.random.default_rng(12)
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=len(text))
+        ok = e.upload_bgzf(0, np.frombuffer(bytes(raw), dtype=np.uint8))
+        assert ok is not None
+        want = e.fetch_bases(0, ok[0]).copy()
+
+        def attempt(buf):
+            got = e.upload_bgzf(0, np.frombuffer(bytes(buf), dtype=np.uint8))
+            if got is None:
+                return None
+            return e.fetch_bases(0, got[0]).copy()
+        first_len = int.from_bytes(raw[16:18], "little") + 1
+        for at in (first_len - 8, first_len - 4, 40, first_len + 18 + 5):        # CRC, ISIZE, data of member 0, data of member 1
+            bad = bytearray(raw)
+            bad[at] ^= 0x5A
+            assert attempt(bad) is None, at
+            assert "member" in e.last_bgzf[3]
+        assert attempt(raw[:len(raw) - 40]) is None                               # cut short
+        assert attempt(b"\x1f\x8b\x08\x00" + bytes(raw[4:])) is None             # no extra field: not BGZF
+        assert attempt(gzip.compress(text)) is None                               # plain gzip
+        same = 0
+        for _ in range(300):
+            bad = bytearray(raw)
+            at = int(rng.integers(0, len(bad)))
+            bad[at] ^= int(rng.integers(1, 256))
+            got = attempt(bad)
+            if got is not None:
+                assert np.array_equal(got, want), at
+                same += 1
+        assert same < 60
+        # the host path still reads the intact file: the same bases
+        n2 = e.upload_text(1, plain, False)[0]
+        assert np.array_equal(e.fetch_bases(1, n2), want)
+
+
 def test_placement_tries_change_nothing_but_time(N, K):
     """KR_OPT_PLACE_TRIES: the pass-1 output buffer is chosen among several allocations (each timed under
     pass 1's write pattern); the result is the same as with a plain allocation"""
