@@ -113,9 +113,16 @@ class BgzfFile:
         return _read_text_host(self.filename)[0]
 
 
-# KRISP_DEVICE_INFLATE=0: BGZF files through the host inflate as before round 6 (A/B, tests)
+# KRISP_DEVICE_INFLATE=0: BGZF files through the host inflate as before round 6 (A/B, tests).  A lane decodes its member
+# in ~40 ms whatever the file's size (profiles/r06/e2e_4x50Mbp.log: a 50 MB text is 800 lanes, a few of the GPU's 256 CUs --
+# 37 ms against 22 on host threads), so the device takes the files whose members fill it: texts of KRISP_DEVICE_INFLATE_MIN
+# bytes and more (default 1 GB = 1.6 x 10^4 members; a 3 GB text: 0.1 s against 1.5 s)
 def device_inflate_on():
     return os.environ.get("KRISP_DEVICE_INFLATE", "1") != "0"
+
+
+def device_inflate_min():
+    return int(os.environ.get("KRISP_DEVICE_INFLATE_MIN", 1 << 30))
 
 
 def read_text(filename):
@@ -127,7 +134,7 @@ def read_text(filename):
         size = os.path.getsize(filename)
         if 28 <= size < (1 << 32) - 64:
             tb = _bgzf_text_bytes(filename, size)
-            if tb is not None and tb < DEVICE_TEXT_MAX:
+            if tb is not None and device_inflate_min() <= tb < DEVICE_TEXT_MAX:
                 t0 = time.time()
                 raw = np.fromfile(filename, dtype=np.uint8)
                 LAST_TIMINGS[os.fspath(filename)] = dict(read_s=time.time() - t0, inflate_s=0.0, parse_s=0.0, members=0,

@@ -334,6 +334,89 @@ def test_kstream_bases_the_strands_do_not_share_equal_the_host_chain(seed, tmp_p
             assert open(out).read().split("\n")[:-1] == want[1]
 
 
+def _bgzf_file(path, data, block=20000):
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for i in list(range(0, len(data), block)) + [None]:
+            ch = b"" if i is None else data[i:i + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cd = co.compress(ch) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd
+                    + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))
+
+
+@pytest.mark.parametrize("name,flow", [("c1_25_1_2", "in_core"), ("c1_25_1_2", "batches"), ("mixed_iupac_6_1_3", "in_core")])
+def test_bgzf_files_are_inflated_on_the_device(name, flow, tmp_path, monkeypatch):
+    """Round 6: a `.gz` file that is BGZF all the way is only READ on the host; the device inflates it, a
+    lane per member (kr_genome_upload_bgzf), and parses it.  The golden cases' genomes as BGZF files through the in-core
+    flow and the streaming flow (the flows whose parse runs on the device; long amplicons and the ranks of a multi-GPU run
+    parse on the host): the reference's output byte for byte, the inflate
+    kernels' time in the files' timings; with KRISP_DEVICE_INFLATE=0 (the host inflates, as for any `.gz`) the same."""
+    import gzip
+    from krisp_amd import fasta
+    case = [c for c in FC if c["name"] == name][0]
+    paths = _paths(case, tmp_path)
+    bg = {}
+    for fn, p in paths.items():
+        opener = gzip.open if p.endswith(".gz") else open
+        with opener(p, "rb") as f:
+            data = f.read()
+        q = str(tmp_path / (fn.split(".")[0] + ".fa.gz"))
+        _bgzf_file(q, data)
+        bg[fn] = q
+    monkeypatch.setenv("KRISP_DEVICE_INFLATE_MIN", "0")
+    if flow == "batches":
+        monkeypatch.setenv("KRISP_STREAM_BATCH", "2")
+    aln = str(tmp_path / "a.txt")
+    argv = [bg[f] for f in case["ingroup"]] + (["--outgroup"] + [bg[f] for f in case["outgroup"]] if case["outgroup"] else []) \
+        + case.get("main_args", []) + ["--out_align", aln]
+    for dev in ("1", "0"):
+        monkeypatch.setenv("KRISP_DEVICE_INFLATE", dev)
+        fasta.LAST_TIMINGS.clear()
+        if "csv" in case:
+            assert _run_main(argv) == case["csv"]
+            assert open(aln).read() == case["align"]
+        else:                           # (the reference's renderer dies on this case's columns: the stages are what is pinned)
+            from krisp_amd import amplicon
+            from krisp_amd import krisp_fasta as KF
+            groups, _ = KF.find_regions([bg[f] for f in case["ingroup"]], [bg[f] for f in case["outgroup"]], case["L"], case["R"],
+                                        _amplicon(case), omit_soft=case["omit_soft"])
+            assert canon_equal(sorted(amplicon.merged_lines(groups)), case["filtered_canon"])
+        tms = [fasta.LAST_TIMINGS[q] for q in bg.values() if q in fasta.LAST_TIMINGS]
+        assert tms and all(bool(t.get("device_inflate")) == (dev == "1") for t in tms), tms
+        if dev == "1":
+            assert all(t.get("device_inflate_s", 0) > 0 and t["members"] >= 2 for t in tms), tms
+
+
+def test_a_damaged_bgzf_file_gets_the_host_paths_verdict(tmp_path, monkeypatch):
+    """a member that does not inflate to its trailer: the device uploads nothing and says so, the file goes through the
+    host inflate as any `.gz` does, and what THAT says about it -- here: an error -- is what the caller sees, the same
+    with the device inflate switched off"""
+    from krisp_amd import krisp_fasta as KF
+    case = [c for c in FC if c["name"] == "c1_25_1_2"][0]
+    paths = _paths(case, tmp_path)
+    import gzip
+    files = []
+    for i, fn in enumerate(case["ingroup"] + case["outgroup"]):
+        with gzip.open(paths[fn], "rb") as f:
+            data = f.read()
+        q = str(tmp_path / f"g{i}.fa.gz")
+        _bgzf_file(q, data)
+        files.append(q)
+    raw = bytearray(open(files[1], "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    open(files[1], "wb").write(bytes(raw))
+    monkeypatch.setenv("KRISP_DEVICE_INFLATE_MIN", "0")
+    seen = []
+    for dev in ("1", "0"):
+        monkeypatch.setenv("KRISP_DEVICE_INFLATE", dev)
+        with pytest.raises(Exception) as ei:
+            KF.find_regions(files[:2], files[2:], 25, 2, 28)
+        seen.append(type(ei.value).__name__)
+    assert seen[0] == seen[1], seen
+
+
 def test_readme_known_answers_on_the_gpu(tmp_path):
     d = os.path.join(GOLDEN, "c1")
     ing = [f"{d}/ingroup{i}.fasta.gz" for i in (0, 1)]

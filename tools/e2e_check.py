@@ -50,7 +50,10 @@ with tempfile.TemporaryDirectory() as td:
             lst.append(q)
     print(f"{ng} x {length / 1e6:g} Mbp; plain {os.path.getsize(plain[0]) / 1e6:.1f} MB, gz {os.path.getsize(gz[0]) / 1e6:.1f} MB, "
           f"bgzf {os.path.getsize(bg[0]) / 1e6:.1f} MB, bz2 {os.path.getsize(bz[0]) / 1e6:.1f} MB per file")
-    for kind, paths in (("fasta.gz", gz), ("bgzf .gz", bg), ("fasta.bz2", bz), ("bz2 x8MB", bzm), ("fasta", plain)):
+    # (round 6: a BGZF file is inflated on the device, kr_genome_upload_bgzf; "bgzf host" = KRISP_DEVICE_INFLATE=0, as before)
+    for kind, paths in (("fasta.gz", gz), ("bgzf .gz", bg), ("bgzf host", bg), ("fasta.bz2", bz), ("bz2 x8MB", bzm), ("fasta", plain)):
+        os.environ["KRISP_DEVICE_INFLATE"] = "0" if kind == "bgzf host" else "1"
+        os.environ["KRISP_DEVICE_INFLATE_MIN"] = "0"          # (whatever the size: the default leaves files below 1 GB of text to the host)
         for rep in range(2):
             fasta.LAST_TIMINGS.clear()
             t0 = time.time()
@@ -59,10 +62,12 @@ with tempfile.TemporaryDirectory() as td:
             csv, align = amplicon.render(groups, [KF.simplename(p) for p in paths[:ng // 2]])
             t2 = time.time()
             tm = list(fasta.LAST_TIMINGS.values())
-            mx = lambda key: max((t[key] for t in tm), default=0.0)  # noqa: E731
+            mx = lambda key: max((t.get(key, 0.0) for t in tm), default=0.0)  # noqa: E731
             print(f"{kind:9s} run {rep}: total {t2 - t0:.3f} s | ingest wall {stats['read_s']:.3f} s "
                   f"(slowest file: read {mx('read_s'):.3f} inflate {mx('inflate_s'):.3f} parse {mx('parse_s'):.3f}; "
-                  f"libdeflate {any(t['libdeflate'] for t in tm)}) | upload+sort+intersect+collect+grouping "
+                  f"libdeflate {any(t['libdeflate'] for t in tm)}"
+                  + (f"; inflate kernels {mx('device_inflate_s'):.4f}" if any('device_inflate_s' in t for t in tm) else "")
+                  + ") | upload+sort+intersect+collect+grouping "
                   f"{stats['device_s']:.3f} s | render {t2 - t1:.3f} s | {stats['kmers']:,} k-mers, {len(groups)} groups")
             if stats.get("stage_s") and stats["device_s"] > 0.15:
                 print("          (device part: " + ", ".join(f"{k} {v:.3f}" for k, v in stats["stage_s"].items()) + ")")

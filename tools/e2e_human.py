@@ -21,14 +21,42 @@ from krisp_amd import krisp_fasta as KF  # noqa: E402
 length = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
 mu = float(sys.argv[2]) if len(sys.argv) > 2 else 2e-4
 ngen = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+as_bgzf = len(sys.argv) > 4 and sys.argv[4] == "bgzf"       # (round 6: BGZF members of 65280 bytes, inflated on the device; "bgzf" as 4th argument)
 t0 = time.time()
 fam = synth.family(5, ngen - 1, 1, length, records=24, mu=mu, snp_every=100_000)
 print(f"{ngen} x {length / 1e9:g} Gbp, mu = {mu:g}: generated in {time.time() - t0:.0f} s", flush=True)
 
 
+class _BgzfWriter:
+    """compressobj-like: the bytes handed over leave as BGZF members of 65280 bytes of text (bgzip's framing)"""
+
+    def __init__(self, level):
+        self.level, self.buf = level, bytearray()
+
+    def _member(self, chunk):
+        import struct
+        co = zlib.compressobj(self.level, zlib.DEFLATED, -15)
+        cd = co.compress(bytes(chunk)) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd
+                + struct.pack("<II", zlib.crc32(bytes(chunk)) & 0xFFFFFFFF, len(chunk)))
+
+    def compress(self, data):
+        self.buf += data
+        out = []
+        while len(self.buf) >= 65280:
+            out.append(self._member(self.buf[:65280]))
+            del self.buf[:65280]
+        return b"".join(out)
+
+    def flush(self):
+        out = (self._member(self.buf) if self.buf else b"") + self._member(b"")
+        self.buf = bytearray()
+        return out
+
+
 def fasta_gz(path, text, width=80, level=1):
-    """80-column FASTA of the records of `text` (records separated by newline), as one gzip member"""
-    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    """80-column FASTA of the records of `text` (records separated by newline), as one gzip member (or as BGZF)"""
+    co = _BgzfWriter(level) if as_bgzf else zlib.compressobj(level, zlib.DEFLATED, 31)
     n = 0
     with open(path, "wb") as f:
         start = 0
@@ -77,9 +105,9 @@ with tempfile.TemporaryDirectory() as td:
         csv, align = amplicon.render(groups, [KF.simplename(p) for p in paths[:ngen - 1]])
         t4 = time.time()
         tm = list(fasta.LAST_TIMINGS.values())
-        mx = lambda key: max((t[key] for t in tm), default=0.0)  # noqa: E731
+        mx = lambda key: max((t.get(key, 0.0) for t in tm), default=0.0)  # noqa: E731
         print(f"run {rep}: total {t4 - t2:.2f} s | ingest wall {stats['read_s']:.2f} s (slowest file: read {mx('read_s'):.2f} inflate "
-              f"{mx('inflate_s'):.2f}) | upload + parse + sort + intersect + collect + grouping {stats['device_s']:.2f} s | render "
+              f"{mx('inflate_s'):.2f}" + (f", inflate kernels {mx('device_inflate_s'):.3f}" if as_bgzf else "") + f") | upload + parse + sort + intersect + collect + grouping {stats['device_s']:.2f} s | render "
               f"{t4 - t3:.2f} s | {stats['kmers']:,} k-mers, {len(groups):,} groups, CSV {len(csv) / 1e6:.1f} MB, alignment {len(align) / 1e6:.1f} MB",
               flush=True)
         print("       device part: " + ", ".join(f"{k} {v:.3f}" for k, v in stats.get("stage_s", {}).items()), flush=True)
