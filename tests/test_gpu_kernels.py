@@ -1,5 +1,7 @@
 """GPU parity: libkrisp_hip.so (through the C ABI) against the packed-key oracle
 (oracle/kmer_oracle.c) on the same seeded inputs.  Bit-exact (integer keys)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -796,6 +798,41 @@ def test_bgzf_inflated_on_the_device_equals_the_host_path(N, what):
             e.sort(0)
             e.sort(1)
             assert e.count(0) == e.count(1)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KR_BGZF_SEEDS", "24"))))
+def test_bgzf_device_inflate_on_random_streams(N, seed):
+    """every compression level, zlib's strategies (default, filtered, Huffman only: no copies; RLE: copies at distance one --
+    the overlapping, byte-wise copy; fixed codes), member sizes from 64 bytes to the format's 65280, texts from sequence
+    files to bytes of every value with repeats at all distances: what the device inflates is what Python's gzip inflates"""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(4400 + seed)
+    kind = seed % 4
+    n = int(rng.integers(1_000, 400_000))
+    if kind == 0:
+        text = _fasta_text(seed, n, nrec=int(rng.integers(1, 6)), width=int(rng.choice([60, 70, 80, 100])))
+    elif kind == 1:                 # a few distinct lines repeated: long copies at many distances
+        lines = [bytes(rng.integers(65, 85, size=int(rng.integers(5, 200)), dtype=np.uint8)) for _ in range(int(rng.integers(2, 30)))]
+        text = b"\n".join(lines[int(i)] for i in rng.integers(0, len(lines), size=max(1, n // 60)))
+    elif kind == 2:
+        text = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+    else:                           # runs of one letter of all lengths
+        text = b"".join(bytes([int(rng.integers(65, 70))]) * int(rng.integers(1, 600)) for _ in range(max(1, n // 300)))
+    level = int(rng.integers(0, 10))
+    strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+    block = int(rng.choice([64, 500, 4096, 30000, 65280]))
+    if level == 0 or kind == 2:
+        block = min(block, 60000)   # (stored or incompressible data: a member must stay below 64 KB)
+    raw = _bgzf(text, block=block, level=level, strategy=strategy, eof=bool(seed % 3))
+    assert gzip.decompress(raw) == text
+    with N.Engine() as e:
+        e.set_params(25, 1, 2, max_bases=max(len(text), 64))
+        got = e.upload_bgzf(0, np.frombuffer(raw, dtype=np.uint8))
+        assert got is not None, (e.last_bgzf, level, strategy, block, kind)
+        want = e.upload_text(1, np.frombuffer(text, dtype=np.uint8), False)
+        assert got[:5] == want
+        assert np.array_equal(e.fetch_bases(0, got[0]), e.fetch_bases(1, want[0]))
 
 
 def test_bgzf_members_that_do_not_inflate_to_their_trailers_go_to_the_host(N):
