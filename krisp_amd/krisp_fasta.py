@@ -717,6 +717,82 @@ def _find_regions_streaming(eng, pool, files, labels, flags, k, geo, omit_soft, 
     return records, touched, sgroups, all(rna), stats
 
 
+def _find_regions_wide_device_ingest(files, ingroup_files, k, geo, omit_soft, device, verbose, do_filter, workers, t0):
+    """find_regions for amplicons longer than one key with the PARSE on the device: the files are read (and inflated) on host
+    threads, every text goes to the device as it is (fasta.ingest_on_device: kr_genome_upload_text, or kr_genome_upload_bgzf
+    for a BGZF file), kr_wide_run follows.  The host sees a genome's bases again only where it needs them -- IUPAC windows
+    (scan_special), mixed DNA / RNA runs, the groups IUPAC windows touch -- through kr_genome_fetch_bases.  Same results as
+    the host-parse flow (KRISP_HOST_PARSE=1 keeps that one: A/B, tests).  -> (groups, stats), or None: take the host parse."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _native
+    Le, De, Re = geo
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        raw = list(pool.map(fasta.read_text, files))
+    labels = ["merged_file"] if len(files) == 1 else [simplename(f) for f in files]
+    ingroup_labels = frozenset(simplename(f) for f in ingroup_files)
+    flags = [lab in ingroup_labels for lab in labels]
+    stats = {"read_s": time.time() - t0}
+    t1 = time.time()
+    budget = int(os.environ.get("KRISP_HBM_BUDGET", "0"))
+    maxb = max(max(len(t) for t, _ in raw), 64)
+    with _native.Engine(device=device, hbm_budget=budget) as eng:
+        eng.set_params_wide(Le, De, Re, omit_soft=omit_soft, max_bases=maxb)
+        nb, rna, specials = [], [], []
+        for i, (text, universal) in enumerate(raw):
+            n, r, sp = fasta.ingest_on_device(eng, i, text, universal, k, omit_soft)
+            nb.append(n)
+            rna.append(bool(r))
+            specials.append([codec.split_window(w, Le, De, Re) for w in sp])
+            raw[i] = None
+        mixed = any(rna) and not all(rna)
+        touched = {(l, r) for sp in specials for (l, d, r) in sp}
+        probes = sorted(p for p in touched if _pure(p[0]) and _pure(p[1]))
+        probe_text = np.frombuffer("\n".join(l + "A" * De + r for l, r in probes).encode(), dtype=np.uint8)
+        if len(probe_text) > maxb:
+            return None
+        texts = None
+
+        def host_texts():
+            nonlocal texts
+            if texts is None:
+                texts = [eng.fetch_bases(i, nb[i]).copy() for i in range(len(files))]
+            return texts
+        ids = list(range(len(files)))
+        if mixed:
+            eng.set_mixed_alphabets(True)
+        nhits = eng.wide_run(ids, flags, apply_filter=do_filter)
+        hits = eng.wide_fetch(_native.WIDE_HITS) if nhits else np.empty(0, dtype=_native.WIDE_HIT)
+        ngroups = int(eng.wide_fetch(_native.WIDE_NGROUPS)[0])
+        counts = eng.wide_fetch(_native.WIDE_COUNTS).tolist()
+        stats["wide_batch"] = int(eng.wide_fetch(_native.WIDE_BATCH_USED)[0])
+        if verbose:
+            for f, cnt in zip(files, counts):
+                print(f"=> Extracted and sorted {cnt:,} {k}-kmers from {f}", file=sys.stderr)
+        finish = _to_rna if all(rna) else (lambda groups: groups)
+        if mixed:
+            groups = _groups_from_hits(hits, host_texts(), labels, Le, De, Re, rna_genomes=rna)
+            groups = [g for g in groups if not (set(g[0].left + g[0].right) & set("TU"))]
+            if do_filter and ingroup_labels:
+                groups = [g for g in groups if amplicon.ingroup_unique_columns(g, ingroup_labels)]
+            if touched:
+                sgroups = _special_groups_wide(eng, host_texts(), labels, specials, touched, probes, probe_text,
+                                               (Le, De, Re), ingroup_labels, do_filter, rna_genomes=rna)
+                groups = _merge_groups(groups, touched | {(g[0].left, g[0].right) for g in sgroups}, sgroups)
+            ngroups = len(groups)
+            finish = lambda g: g        # noqa: E731
+        elif touched:
+            groups = _groups_from_hits(hits, host_texts(), labels, Le, De, Re)
+            sgroups = _special_groups_wide(eng, host_texts(), labels, specials, touched, probes, probe_text,
+                                           (Le, De, Re), ingroup_labels, do_filter)
+            groups = _merge_groups(groups, touched, sgroups)
+        else:
+            rows = eng.wide_windows(k) if nhits else np.empty((0, k), dtype=np.uint8)
+            groups = amplicon.WindowGroups(rows, hits["cand"], hits["genome"], labels, Le, De, Re, rna=all(rna))
+            finish = lambda g: g        # noqa: E731  (the RNA letters are the renderer's)
+    stats.update(device_s=time.time() - t1, kmers=int(sum(counts)) + sum(len(sp) for sp in specials), candidates=ngroups)
+    return finish(groups), stats
+
+
 # ----------------------------------------------------------------------------
 # the fused device flow used by main()
 # ----------------------------------------------------------------------------
@@ -751,6 +827,14 @@ def find_regions(ingroup_files, outgroup_files, L, R, amplicon_len, omit_soft=Fa
         # device, genome by genome as the texts arrive (fasta.ingest_on_device), each followed at once by its sort
         return _find_regions_device_ingest(files, ingroup_files, L, R, k, (Le, De, Re), omit_soft, device, verbose,
                                            do_filter, quirk_all_fail, workers, t0)
+    if wide and not quirk_all_fail and os.environ.get("KRISP_HOST_PARSE") != "1":
+        # round 6: amplicons longer than one key take the device's reader, too (the host's parser was the larger half of such a
+        # run from files: 1.8 of 2.4 s at 8 x 500 Mbp, tools/e2e_profile.py) -- None: a genome set whose IUPAC windows make a
+        # probe text longer than its genomes (tiny inputs): the host parse below
+        got = _find_regions_wide_device_ingest(files, ingroup_files, k, (Le, De, Re), omit_soft, device, verbose, do_filter,
+                                               workers, t0)
+        if got is not None:
+            return got
     # ingest: files are read, inflated and parsed concurrently (the parser releases the GIL)
     with ThreadPoolExecutor(max_workers=workers) as pool:
         loaded = list(pool.map(lambda f: fasta.ingest(f, k, omit_soft), files))

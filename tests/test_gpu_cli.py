@@ -346,11 +346,12 @@ def _bgzf_file(path, data, block=20000):
                     + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))
 
 
-@pytest.mark.parametrize("name,flow", [("c1_25_1_2", "in_core"), ("c1_25_1_2", "batches"), ("mixed_iupac_6_1_3", "in_core")])
+@pytest.mark.parametrize("name,flow", [("c1_25_1_2", "in_core"), ("c1_25_1_2", "batches"), ("mixed_iupac_6_1_3", "in_core"),
+                                       ("c1_30_40_30", "in_core"), ("c1_32_60_32", "in_core")])
 def test_bgzf_files_are_inflated_on_the_device(name, flow, tmp_path, monkeypatch):
     """Round 6: a `.gz` file that is BGZF all the way is only READ on the host; the device inflates it, a
     lane per member (kr_genome_upload_bgzf), and parses it.  The golden cases' genomes as BGZF files through the in-core
-    flow and the streaming flow (the flows whose parse runs on the device; long amplicons and the ranks of a multi-GPU run
+    flow, the streaming flow and the long-amplicon flow (the flows whose parse runs on the device; the ranks of a multi-GPU run
     parse on the host): the reference's output byte for byte, the inflate
     kernels' time in the files' timings; with KRISP_DEVICE_INFLATE=0 (the host inflates, as for any `.gz`) the same."""
     import gzip
