@@ -115,14 +115,16 @@ class BgzfFile:
 
 # KRISP_DEVICE_INFLATE=0: BGZF files through the host inflate as before round 6 (A/B, tests).  A lane decodes its member
 # in ~40 ms whatever the file's size (profiles/r06/e2e_4x50Mbp.log: a 50 MB text is 800 lanes, a few of the GPU's 256 CUs --
-# 37 ms against 22 on host threads), so the device takes the files whose members fill it: texts of KRISP_DEVICE_INFLATE_MIN
-# bytes and more (default 1 GB = 1.6 x 10^4 members; a 3 GB text: 0.1 s against 1.5 s)
+# 37 ms against 22 on host threads), so the device takes the files whose members occupy it: texts of KRISP_DEVICE_INFLATE_MIN
+# bytes and more (default 256 MB = 4 x 10^3 members: 37 ms + a third of the bytes to copy, against 31 ms of all 16 host
+# threads and the whole text to copy -- and the other genomes' files inflate on those threads meanwhile; a 3 GB text: 0.1 s
+# against 0.35 s)
 def device_inflate_on():
     return os.environ.get("KRISP_DEVICE_INFLATE", "1") != "0"
 
 
 def device_inflate_min():
-    return int(os.environ.get("KRISP_DEVICE_INFLATE_MIN", 1 << 30))
+    return int(os.environ.get("KRISP_DEVICE_INFLATE_MIN", 1 << 28))
 
 
 def read_text(filename):
